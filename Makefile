@@ -1,0 +1,34 @@
+# Builds the three shared libraries in-tree:
+#   pathtracer_amd/libptcore.so  HIP kernels + C ABI (gfx950 only)
+#   pathtracer_amd/libpthost.so  C++ host scene layer (links libptcore)
+#   oracle/liboracle.so          CPU oracle, test infrastructure only
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+# FMA contraction off + correctly rounded f32 divide/sqrt: first-hit ids are compared in bits
+HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -std=c++17 -Wall
+HOSTFLAGS = -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -std=c++17 -Wall -Wextra
+
+CORE_SRC = pathtracer_amd/csrc/ptcore.hip
+CORE_DEP = $(wildcard pathtracer_amd/csrc/*.h) include/ptcore.h include/ptscene_src.h
+HOST_DEP = pathtracer_amd/host/pthost.hpp include/pthost.h include/ptcore.h include/ptscene_src.h
+
+all: pathtracer_amd/libptcore.so pathtracer_amd/libpthost.so pathtracer_amd/ptrender oracle
+
+pathtracer_amd/libptcore.so: $(CORE_SRC) $(CORE_DEP)
+	$(HIPCC) $(HIPFLAGS) -o $@ $(CORE_SRC)
+
+pathtracer_amd/libpthost.so: pathtracer_amd/host/pthost.cpp $(HOST_DEP) pathtracer_amd/libptcore.so
+	$(CXX) $(HOSTFLAGS) -o $@ pathtracer_amd/host/pthost.cpp -Lpathtracer_amd -lptcore -Wl,-rpath,'$$ORIGIN'
+
+pathtracer_amd/ptrender: pathtracer_amd/host/ptrender.cpp $(HOST_DEP) pathtracer_amd/libpthost.so
+	$(CXX) -O2 -ffp-contract=off -std=c++17 -Wall -o $@ pathtracer_amd/host/ptrender.cpp -Lpathtracer_amd -lpthost -lptcore -Wl,-rpath,'$$ORIGIN'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f pathtracer_amd/libptcore.so pathtracer_amd/libpthost.so pathtracer_amd/ptrender
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

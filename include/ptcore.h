@@ -1,0 +1,208 @@
+/*
+ * ptcore.h — C ABI of the MI355X path-tracing core (libptcore.so).
+ *
+ * The reference renderer has no FFI or plugin interface; the seam this library sits
+ * behind is the Rust method
+ *
+ *     Camera::render(&self, objects: &PrimitiveBuffer, lights: &LightBuffer,
+ *                    buffer: Arc<Mutex<RgbImage>>)            src/camera.rs:162-167
+ *
+ * called from main() on a dedicated thread (src/main.rs:90-95).  Everything that method
+ * reads is handed over here as plain arrays: the four typed primitive buffers of every
+ * PrimitiveBuffer in post-build order (src/objects.rs:130-136), their flat BVH node
+ * arrays exactly as BVHBuilder::build leaves them (src/bvh.rs:295-311, :667-703), the
+ * instance matrices (src/objects.rs:281-286), the light list (src/objects.rs:208-210),
+ * the materials and textures reachable through Arc<dyn Material>/Arc<dyn Texture>
+ * (src/materials.rs:80-123, src/textures.rs:10-12) and the private fields of Camera
+ * (src/camera.rs:34-61).
+ *
+ * All functions return 0 on success or a PT_ERR_* code; pt_last_error() gives the text.
+ * No function throws, aborts or panics across this boundary.  Host pointers inside the
+ * descriptors are read only during the call that receives them.  A context belongs to
+ * one device and is not re-entrant; use one context per GPU and one process per GPU.
+ * There is no CPU fallback: without a usable HIP device pt_create fails.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ptscene_src.h" /* pts_texture, pts_image, PTS_MAT_*, PTS_TEX_* */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    PT_OK = 0,
+    PT_ERR_INVALID = 1,     /* bad argument / descriptor fails validation */
+    PT_ERR_HIP = 2,         /* a HIP runtime call failed */
+    PT_ERR_NOMEM = 3,       /* device allocation failed */
+    PT_ERR_UNSUPPORTED = 4, /* e.g. instances nested inside instances, non-affine matrix */
+    PT_ERR_STATE = 5        /* call order: render before upload_scene / set_camera */
+};
+
+enum { PT_PRIM_TRI = 0, PT_PRIM_SPHERE = 1, PT_PRIM_QUAD = 2, PT_PRIM_INSTANCE = 3 };
+
+/* One node of InnerPrimitiveBuffer::bvh (FlatBVHNode, src/bvh.rs:667-679) in 32 bytes.
+ * The left child of an interior node is the next node of the array (src/bvh.rs:495). */
+typedef struct pt_node {
+    float bmin[3];
+    float bmax[3];
+    uint32_t a; /* interior: right_child_offset (index within this node array); leaf: offset (first primitive, within its buffer) */
+    uint32_t b; /* interior: axis 0..2;                                        leaf: 0x80000000 | size                          */
+} pt_node;
+#define PT_NODE_LEAF 0x80000000u
+
+/* One InnerPrimitiveBuffer<T> (src/objects.rs:105-109): a slice of the scene-wide
+ * primitive array of its type and, if build_bvh ran, a slice of the node array. */
+typedef struct pt_buffer_desc {
+    uint32_t prim_first, prim_count;
+    uint32_t node_first, node_count; /* node_count == 0: no BVH, linear scan (src/bvh.rs:726-737) */
+} pt_buffer_desc;
+
+/* One PrimitiveBuffer (src/objects.rs:130-136). */
+typedef struct pt_primset_desc {
+    pt_buffer_desc tris, spheres, quads, instances;
+} pt_primset_desc;
+
+/* One Instance (src/objects.rs:281-286). Matrices are row-major 4x4 and must be affine. */
+typedef struct pt_instance_desc {
+    float transform[16];
+    float inverse[16];
+    uint32_t child_set; /* index into sets[]; the child may not contain instances */
+    uint32_t reserved[3];
+} pt_instance_desc;
+
+/* One Arc<dyn Material>. type/texture/p as in pts_material (constructor arguments after
+ * the constructor's own clamping: Metal fuzz in [0,1], Disney specular_transmission >= 1e-4);
+ * derived[] holds what the constructors precompute:
+ *   [0..3] a_x, a_z, inv_a_x, inv_a_z   (DisneyMetal/DisneyGlass::new, src/materials/disney.rs:537-553)
+ *   [4..5] a2, a2_invlog2               (DisneyClearcoat::new, :403-413) */
+typedef struct pt_material_desc {
+    uint32_t type;
+    int32_t texture;
+    float p[14];
+    float derived[8];
+} pt_material_desc;
+
+typedef struct pt_scene_desc {
+    uint32_t n_tris;
+    const float *tri_data;  /* [n][8][3]: Triangle.data, row = px,py,pz,nx,ny,nz,tu,tv; column = vertex (src/objects/tri_mesh.rs:47-72) */
+    const int32_t *tri_mat; /* [n] material index, -1 = None */
+    uint32_t n_spheres;
+    const float *spheres; /* [n][4] center, radius (src/objects/sphere.rs:11-16) */
+    const int32_t *sphere_mat;
+    uint32_t n_quads;
+    const float *quads; /* [n][17] origin, u, v, normal, w, d, area (src/objects/quad_mesh.rs:12-22) */
+    const int32_t *quad_mat;
+    uint32_t n_instances;
+    const pt_instance_desc *instances;
+    uint32_t n_nodes;
+    const pt_node *nodes;
+    uint32_t n_sets;
+    const pt_primset_desc *sets; /* [0] = objects, [1] = LightBuffer.objects (never has BVHs), [2..] = instance children */
+    uint32_t n_materials;
+    const pt_material_desc *materials;
+    uint32_t n_textures;
+    const pts_texture *textures;
+    uint32_t n_images;
+    const pts_image *images;
+    uint64_t n_texel_bytes;
+    const uint8_t *texels;
+} pt_scene_desc;
+
+/* The fields of Camera that render/get_ray/ray_color read (src/camera.rs:34-61). */
+typedef struct pt_camera_desc {
+    uint32_t image_width, image_height;
+    float center[3];
+    float pixel00[3];
+    float pixel_du[3];
+    float pixel_dv[3];
+    float defocus_disk_u[3];
+    float defocus_disk_v[3];
+    float defocus_angle;
+    uint32_t sqrt_spp;
+    float inv_sqrt_spp;
+    uint32_t max_depth;
+    float background[3];
+} pt_camera_desc;
+
+/* Closest hit of one ray: what PrimitiveBuffer::hit returns (src/objects.rs:191-197),
+ * reduced to the identity of the primitive and the ray parameter. */
+typedef struct pt_hit {
+    int32_t prim_type; /* PT_PRIM_TRI/SPHERE/QUAD, -1 = miss */
+    int32_t prim_id;   /* index in its buffer after the BVH build permuted it */
+    int32_t inst_id;   /* index in objects.instances after build, -1 = not inside an instance */
+    float t;           /* ray.t_max on return */
+    float u, v;        /* triangle barycentrics / quad alpha,beta; 0 for spheres */
+} pt_hit;
+
+typedef struct pt_stats {
+    uint64_t rays;            /* rays traced by pt_render since the last reset (all bounces) */
+    uint64_t paths;           /* camera paths started */
+    uint64_t extend_launches; /* launches of the closest-hit kernel that had work */
+    double extend_ms;         /* their summed device time (only with PT_OPT_PROFILE) */
+    double shade_ms;
+    double other_ms;
+    double render_ms;         /* host wall time inside pt_render */
+    /* traversal work, only counted with PT_OPT_COUNTERS: */
+    uint64_t node_tests, tri_tests, sphere_tests, quad_tests;
+    uint64_t device_bytes;    /* device memory held by the context */
+} pt_stats;
+
+enum {
+    PT_OPT_BSDF_SAMPLE_PROBABILITY = 0, /* BSDF_SAMPLE_PROBABILITY of src/camera.rs:317; default 1.0 */
+    PT_OPT_MAX_PATHS = 1,               /* upper bound on paths in flight per batch; default 2^24 */
+    PT_OPT_PROFILE = 2,                 /* 1: bracket kernels with HIP events, fill *_ms */
+    PT_OPT_COUNTERS = 3                 /* 1: count AABB / primitive tests (slower) */
+};
+
+typedef struct pt_context pt_context;
+
+/* Creates a context on HIP device `device`. */
+int pt_create(int device, pt_context **out);
+void pt_destroy(pt_context *ctx);
+const char *pt_last_error(const pt_context *ctx); /* ctx may be NULL: error of the last failed pt_create */
+
+int pt_set_option(pt_context *ctx, int key, double value);
+
+/* Copies the scene to the device (replaces any earlier scene). */
+int pt_upload_scene(pt_context *ctx, const pt_scene_desc *scene);
+/* Sets the camera and (re)allocates + zeroes the accumulator for its resolution. */
+int pt_set_camera(pt_context *ctx, const pt_camera_desc *camera);
+
+/* Camera::render for the strata [stratum_begin, stratum_end) of the s_u-major sample
+ * list (src/camera.rs:176-181); blocking; adds into the accumulator and the pass count
+ * (src/camera.rs:199, :212-217).  The generator is keyed by (seed, pixel, stratum). */
+int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed);
+
+/* As pt_render, but instead of accumulating returns every sample's radiance before the
+ * NaN filter: out[(stratum - stratum_begin) * W*H + pixel][3] (host memory). */
+int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed, float *out);
+
+/* Camera::get_ray for every pixel of one stratum (src/camera.rs:238-260):
+ * rays[W*H][8] = origin, direction, t_min, t_max (host memory). */
+int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *rays);
+
+/* PrimitiveBuffer::hit for n caller-supplied rays: rays[n][8] as above, out[n] (host memory). */
+int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out);
+
+/* Accumulator: W*H*3 f32 sums, row-major (i = u + v*W, src/camera.rs:202-205), and the pass count. */
+int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples);
+/* (sum / n_samples).to_rgb() per pixel (src/camera.rs:221-226, src/types/color.rs:68-78). */
+int pt_read_rgb8(pt_context *ctx, uint8_t *rgb);
+int pt_reset_accum(pt_context *ctx);
+/* Device-to-device copies of the accumulator, for a collective on device memory
+ * (W*H*3 f32).  `stream_sync` semantics: both block until the copy is complete. */
+int pt_copy_accum_to_device(pt_context *ctx, void *dst_device);
+int pt_set_accum_from_device(pt_context *ctx, const void *src_device, uint32_t n_samples);
+
+int pt_stats_get(pt_context *ctx, pt_stats *out);
+int pt_stats_reset(pt_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTCORE_H */

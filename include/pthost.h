@@ -1,0 +1,44 @@
+/*
+ * pthost.h — C entry points of the host scene layer (libpthost.so).
+ *
+ * The host layer restates the reference's scene-side code in C++ (pathtracer_amd/host/):
+ * primitive constructors, Instance transforms, PrimitiveBuffer::build_bvh with the binned
+ * SAH builder of src/bvh.rs:289-516, Camera::new of src/camera.rs:79-144.  These entry
+ * points let a non-C++ caller (the Python tests and benchmark here; a Rust `-sys` crate
+ * in the reference) hand over an authoring-level description and get back the flat,
+ * built arrays that libptcore consumes.
+ */
+#ifndef PTHOST_H
+#define PTHOST_H
+
+#include "ptcore.h"
+#include "ptscene_src.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pth_scene pth_scene;
+
+/* Builds primitives, instance matrices, BVHs (where a set asks for them) and camera
+ * constants from the description.  Returns NULL and fills err on failure — including the
+ * case where the reference would panic (BVH deeper than 63 levels, src/bvh.rs:484-486). */
+pth_scene *pth_scene_build(const pts_scene *scene, const pts_camera *camera, char *err, size_t errlen);
+void pth_scene_free(pth_scene *s);
+
+/* Flat views; valid until pth_scene_free. */
+const pt_scene_desc *pth_scene_desc(const pth_scene *s);
+const pt_camera_desc *pth_camera_desc(const pth_scene *s);
+
+/* perm[i] = insertion index (within its set and type) of the primitive now at position i
+ * of buffer `type` (PT_PRIM_*) of set 0 (objects) or 1 (lights). Returns the length. */
+uint32_t pth_perm(const pth_scene *s, int set, int type, uint32_t *out);
+
+/* Camera::render(objects, lights, buffer): uploads the scene to `ctx`, renders every
+ * stratum of the camera, writes W*H*3 bytes to rgb8.  Returns a PT_ERR_* code. */
+int pth_camera_render(const pth_scene *s, pt_context *ctx, uint64_t seed, uint8_t *rgb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTHOST_H */

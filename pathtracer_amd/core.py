@@ -1,0 +1,284 @@
+"""ctypes bindings of ``libpthost.so`` (host scene layer) and ``libptcore.so`` (HIP kernels).
+
+This is plumbing only: scene construction, BVH building and rendering all happen in the two
+native libraries.  There is no CPU fallback — creating a :class:`Renderer` without a usable
+HIP device raises :class:`PtError`, and a missing library raises ``OSError`` at import of
+the first symbol.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .scene_src import SceneSource, pts_image, pts_texture
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_core: Optional[C.CDLL] = None
+_host: Optional[C.CDLL] = None
+
+PT_NODE_LEAF = 0x80000000
+(PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS) = range(4)
+
+
+class PtError(RuntimeError):
+    pass
+
+
+class pt_node(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("a", C.c_uint32), ("b", C.c_uint32)]
+
+
+class pt_buffer_desc(C.Structure):
+    _fields_ = [("prim_first", C.c_uint32), ("prim_count", C.c_uint32), ("node_first", C.c_uint32), ("node_count", C.c_uint32)]
+
+
+class pt_primset_desc(C.Structure):
+    _fields_ = [("tris", pt_buffer_desc), ("spheres", pt_buffer_desc), ("quads", pt_buffer_desc), ("instances", pt_buffer_desc)]
+
+
+class pt_instance_desc(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("inverse", C.c_float * 16), ("child_set", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class pt_material_desc(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("texture", C.c_int32), ("p", C.c_float * 14), ("derived", C.c_float * 8)]
+
+
+class pt_scene_desc(C.Structure):
+    _fields_ = [
+        ("n_tris", C.c_uint32), ("tri_data", C.POINTER(C.c_float)), ("tri_mat", C.POINTER(C.c_int32)),
+        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(C.c_float)), ("sphere_mat", C.POINTER(C.c_int32)),
+        ("n_quads", C.c_uint32), ("quads", C.POINTER(C.c_float)), ("quad_mat", C.POINTER(C.c_int32)),
+        ("n_instances", C.c_uint32), ("instances", C.POINTER(pt_instance_desc)),
+        ("n_nodes", C.c_uint32), ("nodes", C.POINTER(pt_node)),
+        ("n_sets", C.c_uint32), ("sets", C.POINTER(pt_primset_desc)),
+        ("n_materials", C.c_uint32), ("materials", C.POINTER(pt_material_desc)),
+        ("n_textures", C.c_uint32), ("textures", C.POINTER(pts_texture)),
+        ("n_images", C.c_uint32), ("images", C.POINTER(pts_image)),
+        ("n_texel_bytes", C.c_uint64), ("texels", C.POINTER(C.c_uint8)),
+    ]
+
+
+class pt_camera_desc(C.Structure):
+    _fields_ = [("image_width", C.c_uint32), ("image_height", C.c_uint32), ("center", C.c_float * 3), ("pixel00", C.c_float * 3),
+                ("pixel_du", C.c_float * 3), ("pixel_dv", C.c_float * 3), ("defocus_disk_u", C.c_float * 3),
+                ("defocus_disk_v", C.c_float * 3), ("defocus_angle", C.c_float), ("sqrt_spp", C.c_uint32),
+                ("inv_sqrt_spp", C.c_float), ("max_depth", C.c_uint32), ("background", C.c_float * 3)]
+
+
+class pt_hit(C.Structure):
+    _fields_ = [("prim_type", C.c_int32), ("prim_id", C.c_int32), ("inst_id", C.c_int32), ("t", C.c_float), ("u", C.c_float), ("v", C.c_float)]
+
+
+class pt_stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
+                ("shade_ms", C.c_double), ("other_ms", C.c_double), ("render_ms", C.c_double), ("node_tests", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("quad_tests", C.c_uint64), ("device_bytes", C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
+
+# every symbol include/ptcore.h and include/pthost.h declare
+CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render",
+                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum",
+                "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
+HOST_SYMBOLS = ["pth_scene_build", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render"]
+
+
+def core_lib() -> C.CDLL:
+    global _core
+    if _core is None:
+        L = C.CDLL(os.path.join(_HERE, "libptcore.so"), mode=C.RTLD_GLOBAL)
+        vp = C.c_void_p
+        L.pt_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.pt_destroy.argtypes = [vp]
+        L.pt_destroy.restype = None
+        L.pt_last_error.argtypes = [vp]
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_set_option.argtypes = [vp, C.c_int, C.c_double]
+        L.pt_upload_scene.argtypes = [vp, vp]
+        L.pt_set_camera.argtypes = [vp, vp]
+        L.pt_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.pt_render_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
+        L.pt_generate_rays.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
+        L.pt_trace_first_hit.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pt_read_accum.argtypes = [vp, vp, vp]
+        L.pt_read_rgb8.argtypes = [vp, vp]
+        L.pt_reset_accum.argtypes = [vp]
+        L.pt_copy_accum_to_device.argtypes = [vp, vp]
+        L.pt_set_accum_from_device.argtypes = [vp, vp, C.c_uint32]
+        L.pt_stats_get.argtypes = [vp, vp]
+        L.pt_stats_reset.argtypes = [vp]
+        _core = L
+    return _core
+
+
+def host_lib() -> C.CDLL:
+    global _host
+    if _host is None:
+        core_lib()
+        L = C.CDLL(os.path.join(_HERE, "libpthost.so"))
+        vp = C.c_void_p
+        L.pth_scene_build.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
+        L.pth_scene_build.restype = vp
+        L.pth_scene_free.argtypes = [vp]
+        L.pth_scene_free.restype = None
+        L.pth_scene_desc.argtypes = [vp]
+        L.pth_scene_desc.restype = C.POINTER(pt_scene_desc)
+        L.pth_camera_desc.argtypes = [vp]
+        L.pth_camera_desc.restype = C.POINTER(pt_camera_desc)
+        L.pth_perm.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.pth_perm.restype = C.c_uint32
+        L.pth_camera_render.argtypes = [vp, vp, C.c_uint64, vp]
+        _host = L
+    return _host
+
+
+def _arr(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("bmax", np.float32, 3), ("a", np.uint32), ("b", np.uint32)])
+
+
+class HostScene:
+    """A scene after the host layer built it: primitives in post-build order, flat BVHs, camera constants."""
+
+    def __init__(self, src: SceneSource):
+        self.src = src
+        sc, cam = src.to_c()
+        err = C.create_string_buffer(512)
+        self.h = host_lib().pth_scene_build(C.byref(sc), C.byref(cam), err, 512)
+        if not self.h:
+            raise PtError("pth_scene_build: " + err.value.decode())
+        self.desc = host_lib().pth_scene_desc(self.h).contents
+        self.camera = host_lib().pth_camera_desc(self.h).contents
+        self.width, self.height = self.camera.image_width, self.camera.image_height
+        self.sqrt_spp = self.camera.sqrt_spp
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host_lib().pth_scene_free(self.h)
+            self.h = None
+
+    # --- views of the flat description (read-only numpy copies) -------------------------
+    def set_desc(self, k: int) -> pt_primset_desc:
+        return self.desc.sets[k]
+
+    def nodes(self, buf: pt_buffer_desc) -> np.ndarray:
+        allnodes = _arr(self.desc.nodes, (self.desc.n_nodes,), NODE_DTYPE)
+        return allnodes[buf.node_first:buf.node_first + buf.node_count].copy()
+
+    def quads(self, buf: pt_buffer_desc) -> np.ndarray:
+        q = _arr(self.desc.quads, (self.desc.n_quads, 17), np.float32)
+        return q[buf.prim_first:buf.prim_first + buf.prim_count].copy()
+
+    def triangles(self, buf: pt_buffer_desc) -> np.ndarray:
+        t = _arr(self.desc.tri_data, (self.desc.n_tris, 24), np.float32)
+        return t[buf.prim_first:buf.prim_first + buf.prim_count].copy()
+
+    def instances(self, buf: pt_buffer_desc) -> np.ndarray:
+        out = np.zeros((buf.prim_count, 32), np.float32)
+        for k in range(buf.prim_count):
+            inst = self.desc.instances[buf.prim_first + k]
+            out[k, :16] = inst.transform[:]
+            out[k, 16:] = inst.inverse[:]
+        return out
+
+    def perm(self, set_: int, type_: int) -> np.ndarray:
+        n = host_lib().pth_perm(self.h, set_, type_, None)
+        out = np.zeros(n, np.uint32)
+        if n:
+            host_lib().pth_perm(self.h, set_, type_, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def camera_constants(self) -> np.ndarray:
+        c = self.camera
+        return np.array([c.image_width, c.image_height, *c.center, *c.pixel00, *c.pixel_du, *c.pixel_dv, *c.defocus_disk_u,
+                         *c.defocus_disk_v, c.defocus_angle, c.sqrt_spp, c.inv_sqrt_spp, c.max_depth, *c.background], np.float32)
+
+
+class Renderer:
+    """One ``pt_context`` on one GPU with a scene and a camera loaded."""
+
+    def __init__(self, scene: HostScene, device: int = 0):
+        self.scene = scene
+        self.L = core_lib()
+        h = C.c_void_p()
+        rc = self.L.pt_create(device, C.byref(h))
+        if rc:
+            raise PtError("pt_create: " + self.L.pt_last_error(None).decode())
+        self.ctx = h
+        self._check(self.L.pt_upload_scene(self.ctx, C.byref(scene.desc)), "pt_upload_scene")
+        self._check(self.L.pt_set_camera(self.ctx, C.byref(scene.camera)), "pt_set_camera")
+        self.width, self.height, self.sqrt_spp = scene.width, scene.height, scene.sqrt_spp
+        self.npix = self.width * self.height
+
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise PtError(f"{what} failed ({rc}): " + self.L.pt_last_error(self.ctx).decode())
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.pt_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        self.close()
+
+    def set_option(self, key: int, value: float):
+        self._check(self.L.pt_set_option(self.ctx, key, float(value)), "pt_set_option")
+
+    def render(self, stratum_begin: int, stratum_end: int, seed: int = 0):
+        self._check(self.L.pt_render(self.ctx, stratum_begin, stratum_end, seed), "pt_render")
+
+    def render_samples(self, stratum_begin: int, stratum_end: int, seed: int = 0) -> np.ndarray:
+        out = np.zeros((stratum_end - stratum_begin, self.npix, 3), np.float32)
+        self._check(self.L.pt_render_samples(self.ctx, stratum_begin, stratum_end, seed, out.ctypes.data_as(C.c_void_p)), "pt_render_samples")
+        return out
+
+    def generate_rays(self, stratum: int, seed: int = 0) -> np.ndarray:
+        out = np.zeros((self.npix, 8), np.float32)
+        self._check(self.L.pt_generate_rays(self.ctx, stratum, seed, out.ctypes.data_as(C.c_void_p)), "pt_generate_rays")
+        return out
+
+    def trace(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], HIT_DTYPE)
+        self._check(self.L.pt_trace_first_hit(self.ctx, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p)), "pt_trace_first_hit")
+        return out
+
+    def read_accum(self):
+        acc = np.zeros((self.npix, 3), np.float32)
+        n = C.c_uint32(0)
+        self._check(self.L.pt_read_accum(self.ctx, acc.ctypes.data_as(C.c_void_p), C.byref(n)), "pt_read_accum")
+        return acc, int(n.value)
+
+    def read_rgb8(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        self._check(self.L.pt_read_rgb8(self.ctx, out.ctypes.data_as(C.c_void_p)), "pt_read_rgb8")
+        return out
+
+    def reset_accum(self):
+        self._check(self.L.pt_reset_accum(self.ctx), "pt_reset_accum")
+
+    def copy_accum_to_device(self, device_ptr: int):
+        self._check(self.L.pt_copy_accum_to_device(self.ctx, C.c_void_p(device_ptr)), "pt_copy_accum_to_device")
+
+    def set_accum_from_device(self, device_ptr: int, n_samples: int):
+        self._check(self.L.pt_set_accum_from_device(self.ctx, C.c_void_p(device_ptr), n_samples), "pt_set_accum_from_device")
+
+    def stats(self) -> dict:
+        s = pt_stats()
+        self._check(self.L.pt_stats_get(self.ctx, C.byref(s)), "pt_stats_get")
+        return {k: getattr(s, k) for k, _ in pt_stats._fields_}
+
+    def stats_reset(self):
+        self._check(self.L.pt_stats_reset(self.ctx), "pt_stats_reset")

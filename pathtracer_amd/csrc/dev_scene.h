@@ -1,0 +1,92 @@
+// Device-resident scene layout (HBM) and the per-path state arrays.
+//
+//   nodes      2 x float4 per BVH node (32 B): (min.xyz, max.x) (max.yz, a, b)      — see pt_node
+//   tri_hot    3 x float4 per triangle (48 B, 36 used): v0, e1 = v1-v0, e2 = v2-v0   — all the intersector reads
+//   tri_cold   6 x float4 per triangle (96 B): the 8x3 attribute matrix, fetched once per path vertex
+//   spheres    1 x float4 (center, radius)
+//   quads      4 x float4 (64 B): (origin, u.x) (u.yz, v.xy) (v.z, normal) (w, d)
+//   insts      7 x float4 (112 B): inverse 3x4, transform 3x4, (child_set, -, -, -)
+// Primitive indices stored in hit records are scene-wide ("global") indices into these arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptcore.h"
+#include "dev_math.h"
+
+namespace ptd {
+
+struct DevBuffer {
+    uint32_t prim_first, prim_count, node_first, node_count;
+};
+struct DevSet {
+    DevBuffer tris, spheres, quads, insts;
+};
+
+struct DevMaterial {  // 96 B, same field order as pt_material_desc
+    uint32_t type;
+    int32_t texture;
+    float p[14];
+    float derived[8];
+};
+
+struct DevScene {
+    const float4 *nodes;
+    const float4 *tri_hot;
+    const float4 *tri_cold;
+    const int32_t *tri_mat;
+    const float4 *spheres;
+    const int32_t *sphere_mat;
+    const float4 *quads;
+    const float *quad_area;
+    const int32_t *quad_mat;
+    const float4 *insts;
+    const DevSet *sets;
+    const DevMaterial *mats;
+    const uint8_t *mat_queue;  // material index -> shade queue slot
+    const pts_texture *textures;
+    const pts_image *images;
+    const uint8_t *texels;
+    DevSet world;   // sets[0]
+    DevSet lights;  // sets[1]
+    uint32_t n_materials;
+    uint32_t n_light_total;  // lights.len() including instances
+};
+
+struct DevCamera {
+    uint32_t width, height;
+    f3 center, pixel00, pixel_du, pixel_dv, disk_u, disk_v;
+    float defocus_angle;
+    uint32_t sqrt_spp;
+    float inv_sqrt_spp;
+    uint32_t max_depth;
+    f3 background;
+};
+
+// hit2 encoding: bits 0..1 primitive type, bits 2..31 instance index + 1 (0 = not in an instance)
+#define PTD_HIT_MISS 0xFFFFFFFFu
+
+constexpr int MAX_QUEUES = PTS_MAT_COUNT;
+
+// Device-side launch bookkeeping.  Counters with two copies are used in ping-pong by
+// bounce parity so that a kernel can clear the copy the next kernel will fill.
+struct DevCounters {
+    uint32_t ray_count[2];                // entries in ray queue [parity]
+    uint32_t shade_count[2][MAX_QUEUES];  // entries per material queue [parity][slot]
+};
+
+// Per-path state, indexed by slot = (stratum - batch_first_stratum) * W*H + pixel.
+struct PathState {
+    float4 *ray_o;    // origin.xyz, rng draw counter (bits)
+    float4 *ray_d;    // direction.xyz, remaining depth (bits)
+    float4 *beta;     // path throughput so far
+    float4 *hit;      // t, u, v, global primitive index (bits)
+    uint32_t *hit2;   // type | (instance+1) << 2, or PTD_HIT_MISS
+    float4 *contrib;  // radiance of the finished path (xyz)
+    uint32_t *ray_queue[2];
+    uint32_t *shade_queue[MAX_QUEUES];  // capacity n_slots each, only used slots allocated
+    DevCounters *ctr;
+    uint32_t n_slots;
+};
+
+}  // namespace ptd

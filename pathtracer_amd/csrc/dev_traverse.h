@@ -1,0 +1,293 @@
+// Closest-hit search on the device: slab test, the three intersectors, flat-BVH
+// traversal and instance descent.
+//
+// Order of operations follows the reference so that the same primitives are tested
+// in the same sequence with the same f32 arithmetic:
+//   BBox::intersect                       src/bvh.rs:145-182
+//   InnerPrimitiveBuffer::traverse        src/bvh.rs:725-797   (near child first by sign of
+//                                         the split axis, far child pushed, leaf in order,
+//                                         a candidate with t == t_max is accepted)
+//   Triangle::hit                         src/objects/tri_mesh.rs:167-198
+//   Sphere::hit                           src/objects/sphere.rs:57-80
+//   Quad::hit                             src/objects/quad_mesh.rs:126-147
+//   Instance::hit                         src/objects.rs:384-401
+//   PrimitiveBuffer::hit                  src/objects.rs:191-197 (triangles, spheres, quads, instances)
+//
+// Each lane keeps its traversal stack in LDS (one bank column per lane, so pushes and
+// pops never conflict); entries beyond LDS_LEVELS spill to a private array that real
+// scenes do not reach.
+#pragma once
+#include "dev_scene.h"
+
+namespace ptd {
+
+constexpr int BLOCK = 256;       // threads per workgroup of the traversal kernels
+constexpr int LDS_LEVELS = 32;   // stack entries per lane held in LDS (32 KB per workgroup)
+constexpr int SPILL_LEVELS = 96; // 64 levels per BVH x 2 nesting levels in the worst case
+
+struct TravRay {
+    f3 o, d, inv_d;
+    float t_min, t_max;
+};
+__device__ __forceinline__ TravRay make_trav_ray(f3 o, f3 d, float t_min, float t_max) {
+    TravRay r;
+    r.o = o;
+    r.d = d;
+    r.inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // `1.0 / ray.direction[axis]`, same value at every node
+    r.t_min = t_min;
+    r.t_max = t_max;
+    return r;
+}
+
+struct HitState {
+    float u, v;        // barycentrics (triangle) / alpha, beta (quad)
+    uint32_t prim;     // global primitive index
+    uint32_t code;     // type | (instance+1) << 2, PTD_HIT_MISS while nothing was hit
+};
+
+struct TravCounters {
+    uint32_t nodes, tris, spheres, quads;
+};
+
+struct LaneStack {
+    uint32_t *lds;  // &stack[0][threadIdx.x]; level stride = BLOCK
+    uint32_t spill[SPILL_LEVELS];
+    int sp;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (sp < LDS_LEVELS) lds[sp * BLOCK] = v;
+        else spill[sp - LDS_LEVELS] = v;
+        sp++;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        sp--;
+        return sp < LDS_LEVELS ? lds[sp * BLOCK] : spill[sp - LDS_LEVELS];
+    }
+};
+
+// Per-axis update of BBox::intersect; both arms of `if t0 < t1` assign the smaller of
+// (t0,t1) to the entry side and the larger to the exit side, and a NaN takes the else arm.
+__device__ __forceinline__ void slab_axis(float lo, float hi, float o, float inv, float &t_min, float &t_max) {
+    float t0 = (lo - o) * inv;
+    float t1 = (hi - o) * inv;
+    bool lt = t0 < t1;
+    float tn = lt ? t0 : t1;
+    float tf = lt ? t1 : t0;
+    if (tn > t_min) t_min = tn;
+    if (tf < t_max) t_max = tf;
+}
+// The reference leaves the loop at the first axis with t_max < t_min; t_min only grows and
+// t_max only shrinks, so testing once after the third axis gives the same answer.
+__device__ __forceinline__ bool slab_test(float4 n0, float4 n1, const TravRay &r) {
+    float t_min = r.t_min, t_max = r.t_max;
+    slab_axis(n0.x, n0.w, r.o.x, r.inv_d.x, t_min, t_max);
+    slab_axis(n0.y, n1.x, r.o.y, r.inv_d.y, t_min, t_max);
+    slab_axis(n0.z, n1.y, r.o.z, r.inv_d.z, t_min, t_max);
+    return !(t_max < t_min);
+}
+
+template <int TYPE>
+__device__ __forceinline__ void hit_prim(const DevScene &sc, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code,
+                                         TravCounters &tc);
+
+template <>
+__device__ __forceinline__ void hit_prim<PT_PRIM_TRI>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
+                                                      uint32_t inst_code, TravCounters &tc) {
+    tc.tris++;
+    const float4 a = sc.tri_hot[3 * g], b = sc.tri_hot[3 * g + 1], c = sc.tri_hot[3 * g + 2];
+    f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+    f3 e1_x_d = cross(e1, r.d);
+    float triple = dot(e1_x_d, e2);
+    if (triple == 0.0f) return;
+    float inv_triple = 1.0f / triple;
+    f3 s = r.o - v0;
+    f3 e2_x_s = cross(e2, s);
+    float u = dot(e2_x_s, r.d) * inv_triple;
+    if (u < 0.0f || u > 1.0f) return;
+    float v = dot(e1_x_d, s) * inv_triple;
+    if (v < 0.0f || u + v > 1.0f) return;
+    float t = dot(e2_x_s, e1) * inv_triple;
+    if (!(r.t_min <= t && t <= r.t_max)) return;
+    r.t_max = t;
+    h.u = u;
+    h.v = v;
+    h.prim = g;
+    h.code = PT_PRIM_TRI | inst_code;
+}
+
+template <>
+__device__ __forceinline__ void hit_prim<PT_PRIM_SPHERE>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
+                                                         uint32_t inst_code, TravCounters &tc) {
+    tc.spheres++;
+    const float4 s = sc.spheres[g];
+    f3 oc = mk3(s.x, s.y, s.z) - r.o;
+    float a = norm_squared(r.d);
+    float hh = dot(r.d, oc);
+    float c = norm_squared(oc) - s.w * s.w;
+    float discriminant = hh * hh - a * c;
+    if (discriminant < 0.0f) return;
+    float sqrt_disc = sqrtf(discriminant);
+    float root = (hh - sqrt_disc) / a;
+    if (root < r.t_min || r.t_max < root) {
+        root = (hh + sqrt_disc) / a;
+        if (root < r.t_min || r.t_max < root) return;
+    }
+    r.t_max = root;
+    h.u = 0.0f;
+    h.v = 0.0f;
+    h.prim = g;
+    h.code = PT_PRIM_SPHERE | inst_code;
+}
+
+template <>
+__device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
+                                                       uint32_t inst_code, TravCounters &tc) {
+    tc.quads++;
+    const float4 q0 = sc.quads[4 * g], q1 = sc.quads[4 * g + 1], q2 = sc.quads[4 * g + 2], q3 = sc.quads[4 * g + 3];
+    f3 origin = mk3(q0.x, q0.y, q0.z), qu = mk3(q0.w, q1.x, q1.y), qv = mk3(q1.z, q1.w, q2.x);
+    f3 normal = mk3(q2.y, q2.z, q2.w), w = mk3(q3.x, q3.y, q3.z);
+    float d = q3.w;
+    float denom = dot(normal, r.d);
+    if (fabsf(denom) < 1e-6f) return;
+    float t = (d - dot(normal, r.o)) / denom;
+    if (t < r.t_min || t > r.t_max) return;
+    f3 intersection = r.o + t * r.d;
+    f3 p = intersection - origin;
+    float alpha = dot(w, cross(p, qv));
+    float beta = dot(w, cross(qu, p));
+    if (!(0.0f <= alpha && alpha <= 1.0f) || !(0.0f <= beta && beta <= 1.0f)) return;
+    r.t_max = t;
+    h.u = alpha;
+    h.v = beta;
+    h.prim = g;
+    h.code = PT_PRIM_QUAD | inst_code;
+}
+
+// One InnerPrimitiveBuffer: flat-BVH traversal, or the linear scan when it has no BVH.
+template <int TYPE>
+__device__ __forceinline__ void traverse_buffer(const DevScene &sc, const DevBuffer &buf, TravRay &r, HitState &h,
+                                                uint32_t inst_code, LaneStack &st, TravCounters &tc) {
+    if (buf.prim_count == 0) return;
+    if (buf.node_count == 0) {
+        for (uint32_t i = 0; i < buf.prim_count; i++) hit_prim<TYPE>(sc, buf.prim_first + i, r, h, inst_code, tc);
+        return;
+    }
+    const bool neg_x = r.d.x < 0.0f, neg_y = r.d.y < 0.0f, neg_z = r.d.z < 0.0f;
+    const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
+    const int sp0 = st.sp;
+    uint32_t cur = 0;
+    for (;;) {
+        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+        tc.nodes++;
+        bool descend = false;
+        if (slab_test(n0, n1, r)) {
+            const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
+            if (!(b & PT_NODE_LEAF)) {
+                const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
+                if (neg) {
+                    st.push(cur + 1);
+                    cur = a;
+                } else {
+                    st.push(a);
+                    cur = cur + 1;
+                }
+                descend = true;
+            } else {
+                const uint32_t cnt = b & 0xFFFFu;
+                for (uint32_t i = 0; i < cnt; i++) hit_prim<TYPE>(sc, buf.prim_first + a + i, r, h, inst_code, tc);
+            }
+        }
+        if (!descend) {
+            if (st.sp == sp0) break;
+            cur = st.pop();
+        }
+    }
+}
+
+// The triangle, sphere and quad buffers of one PrimitiveBuffer, in that order.
+__device__ __forceinline__ void hit_set_prims(const DevScene &sc, const DevSet &set, TravRay &r, HitState &h,
+                                              uint32_t inst_code, LaneStack &st, TravCounters &tc) {
+    traverse_buffer<PT_PRIM_TRI>(sc, set.tris, r, h, inst_code, st, tc);
+    traverse_buffer<PT_PRIM_SPHERE>(sc, set.spheres, r, h, inst_code, st, tc);
+    traverse_buffer<PT_PRIM_QUAD>(sc, set.quads, r, h, inst_code, st, tc);
+}
+
+__device__ __forceinline__ Affine load_affine(const float4 *p) {
+    Affine a;
+    const float4 r0 = p[0], r1 = p[1], r2 = p[2];
+    a.m[0] = r0.x; a.m[1] = r0.y; a.m[2] = r0.z; a.m[3] = r0.w;
+    a.m[4] = r1.x; a.m[5] = r1.y; a.m[6] = r1.z; a.m[7] = r1.w;
+    a.m[8] = r2.x; a.m[9] = r2.y; a.m[10] = r2.z; a.m[11] = r2.w;
+    return a;
+}
+
+// Instance::hit: the ray is taken into the instance's frame without renormalising the
+// direction, so t is shared between the two frames.
+__device__ __forceinline__ void hit_instance(const DevScene &sc, uint32_t gi, TravRay &r, HitState &h, LaneStack &st,
+                                             TravCounters &tc) {
+    const float4 *ip = sc.insts + 7 * (size_t)gi;
+    const Affine inv = load_affine(ip);
+    const uint32_t child = __float_as_uint(ip[6].x);
+    TravRay local = make_trav_ray(xf_point(inv, r.o), xf_vector(inv, r.d), r.t_min, r.t_max);
+    const uint32_t before = h.code;
+    HitState hl = h;
+    hl.code = PTD_HIT_MISS;
+    const DevSet set = sc.sets[child];
+    hit_set_prims(sc, set, local, hl, (gi - sc.world.insts.prim_first + 1u) << 2, st, tc);
+    if (hl.code != PTD_HIT_MISS) {
+        h = hl;
+        r.t_max = local.t_max;
+    } else {
+        h.code = before;
+    }
+}
+
+__device__ __forceinline__ void traverse_instances(const DevScene &sc, const DevBuffer &buf, TravRay &r, HitState &h,
+                                                   LaneStack &st, TravCounters &tc) {
+    if (buf.prim_count == 0) return;
+    if (buf.node_count == 0) {
+        for (uint32_t i = 0; i < buf.prim_count; i++) hit_instance(sc, buf.prim_first + i, r, h, st, tc);
+        return;
+    }
+    const bool neg_x = r.d.x < 0.0f, neg_y = r.d.y < 0.0f, neg_z = r.d.z < 0.0f;
+    const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
+    const int sp0 = st.sp;
+    uint32_t cur = 0;
+    for (;;) {
+        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+        tc.nodes++;
+        bool descend = false;
+        if (slab_test(n0, n1, r)) {
+            const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
+            if (!(b & PT_NODE_LEAF)) {
+                const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
+                if (neg) {
+                    st.push(cur + 1);
+                    cur = a;
+                } else {
+                    st.push(a);
+                    cur = cur + 1;
+                }
+                descend = true;
+            } else {
+                const uint32_t cnt = b & 0xFFFFu;
+                for (uint32_t i = 0; i < cnt; i++) hit_instance(sc, buf.prim_first + a + i, r, h, st, tc);
+            }
+        }
+        if (!descend) {
+            if (st.sp == sp0) break;
+            cur = st.pop();
+        }
+    }
+}
+
+// PrimitiveBuffer::hit on the world set. On return r.t_max is the hit distance (or the
+// incoming t_max on a miss) and h identifies the primitive.
+__device__ __forceinline__ void hit_world(const DevScene &sc, TravRay &r, HitState &h, LaneStack &st, TravCounters &tc) {
+    h.code = PTD_HIT_MISS;
+    h.u = h.v = 0.0f;
+    h.prim = 0;
+    hit_set_prims(sc, sc.world, r, h, 0u, st, tc);
+    traverse_instances(sc, sc.world.insts, r, h, st, tc);
+}
+
+}  // namespace ptd

@@ -1,0 +1,1040 @@
+// libptcore: the MI355X (gfx950) path-tracing core behind include/ptcore.h.
+//
+// Wavefront organisation of Camera::render (src/camera.rs:162-236) and the recursion of
+// Camera::ray_color (src/camera.rs:262-373), unrolled: a batch holds every pixel of k
+// consecutive strata as independent paths; per bounce one `extend` launch finds closest
+// hits for the live rays and sorts the paths by material type into per-type queues, and
+// one `shade_<material>` launch per material type present in the scene evaluates the
+// vertex, applies Russian roulette and appends the survivors to the next ray queue.
+// Queue tails are reserved with one atomic per wave (wave64 ballot + mbcnt prefix).
+// Launch sizes are read from device memory, so a whole batch is enqueued without any
+// host synchronisation.  Finished paths leave their radiance in a per-path slot and a
+// final kernel adds the slots of each pixel in stratum order, so the accumulator is
+// deterministic and sums in the order the reference does.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dev_shade.h"
+
+using namespace ptd;
+
+// ============================================================================ kernels
+
+struct DevStats {
+    unsigned long long rays_total, paths_total, extend_nonempty;
+    unsigned long long node_tests, tri_tests, sphere_tests, quad_tests;
+};
+
+struct BatchParams {
+    uint64_t seed_mixed;
+    uint32_t stratum_first;  // first stratum of this batch
+    uint32_t npix;
+    uint32_t n_slots;
+    float bsdf_prob;
+};
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Appends `id` to a queue for every lane with want == true: one atomic per wave reserves
+// the range, each lane's position inside it is its rank among the wanting lanes.
+__device__ __forceinline__ void wave_push(bool want, uint32_t id, uint32_t *queue, uint32_t *count) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const uint32_t total = (uint32_t)__popcll(mask);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(count, total);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (want) queue[base + rank] = id;
+}
+
+// Camera::get_ray (src/camera.rs:238-260) for one (pixel, stratum).
+__device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint32_t pixel, uint32_t stratum, f3 &o, f3 &d) {
+    const float u = (float)(pixel % cam.width), v = (float)(pixel / cam.width);
+    const float s_u = (float)(stratum / cam.sqrt_spp), s_v = (float)(stratum % cam.sqrt_spp);
+    float disk_u, disk_v;
+    for (;;) {  // DiskSampler::unit(), src/types/sampler.rs:49-58: drawn even when there is no lens
+        float x = rng.range(-1.0f, 1.0f);
+        float y = rng.range(-1.0f, 1.0f);
+        if (x * x + y * y < 1.0f) {
+            disk_u = x;
+            disk_v = y;
+            break;
+        }
+    }
+    f3 ray_center = cam.center;
+    if (!(cam.defocus_angle <= 0.0f)) ray_center = cam.center + disk_u * cam.disk_u + disk_v * cam.disk_v;
+    const float sx = rng.range(0.0f, 1.0f);  // SquareSampler((0.5, 0.5), 0.5)
+    const float sy = rng.range(0.0f, 1.0f);
+    const float offset_u = (s_u + sx) * cam.inv_sqrt_spp - 0.5f;
+    const float offset_v = (s_v + sy) * cam.inv_sqrt_spp - 0.5f;
+    const f3 pixel_center = cam.pixel00 + (u + offset_u) * cam.pixel_du + (v + offset_v) * cam.pixel_dv;
+    o = ray_center;
+    d = pixel_center - ray_center;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, BatchParams bp, DevStats *stats) {
+    const uint32_t n = bp.n_slots;
+    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n; slot += gridDim.x * BLOCK) {
+        const uint32_t pixel = slot % bp.npix, stratum = bp.stratum_first + slot / bp.npix;
+        Rng rng;
+        rng.init(bp.seed_mixed, pixel, stratum, 0u);
+        f3 o, d;
+        camera_ray(cam, rng, pixel, stratum, o, d);
+        ps.ray_o[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.counter));
+        ps.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cam.max_depth));
+        ps.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        ps.contrib[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ps.ray_queue[0][slot] = slot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ps.ctr->ray_count[0] = n;
+        atomicAdd(&stats->paths_total, (unsigned long long)n);
+    }
+}
+
+// Rays only (pt_generate_rays).
+__global__ __launch_bounds__(BLOCK) void k_raygen_only(DevCamera cam, BatchParams bp, float *rays) {
+    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < bp.npix; pixel += gridDim.x * BLOCK) {
+        Rng rng;
+        rng.init(bp.seed_mixed, pixel, bp.stratum_first, 0u);
+        f3 o, d;
+        camera_ray(cam, rng, pixel, bp.stratum_first, o, d);
+        float *r = rays + 8 * (size_t)pixel;
+        r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = 0.001f; r[7] = INFINITY;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, 64);
+    return v;
+}
+
+// Closest hit for every ray of the current queue (PrimitiveBuffer::hit, src/objects.rs:191-197).
+// Missed paths and paths that hit a primitive without material finish here
+// (src/camera.rs:371, :277-283); the others are sorted by material type.
+template <bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+    __shared__ uint32_t s_stack[LDS_LEVELS * BLOCK];
+    const uint32_t n = ps.ctr->ray_count[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ps.ctr->ray_count[parity ^ 1u] = 0u;
+        if (n) {
+            atomicAdd(&stats->rays_total, (unsigned long long)n);
+            atomicAdd(&stats->extend_nonempty, 1ull);
+        }
+    }
+    LaneStack st;
+    st.lds = s_stack + threadIdx.x;
+    st.sp = 0;
+    TravCounters tc{0, 0, 0, 0};
+    const uint32_t *queue = ps.ray_queue[parity];
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool active = i < n;
+        uint32_t slot = 0, qslot = 0xFFu;
+        if (active) {
+            slot = queue[i];
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            HitState h;
+            hit_world(sc, r, h, st, tc);
+            ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+            ps.hit2[slot] = h.code;
+            {
+                int32_t mat = -1;
+                if (h.code != PTD_HIT_MISS) {
+                    const uint32_t type = h.code & 3u;
+                    mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
+                }
+                if (mat >= 0) {
+                    qslot = sc.mat_queue[mat];
+                } else {
+                    const float4 b = ps.beta[slot];
+                    const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
+                    ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+                }
+            }
+        }
+        {
+            // one pass per material queue that some lane of this wave needs
+            unsigned long long todo = __ballot(qslot != 0xFFu);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t q = (uint32_t)__shfl((int)qslot, leader, 64);
+                const bool mine = qslot == q;
+                wave_push(mine, slot, ps.shade_queue[q], &ps.ctr->shade_count[parity][q]);
+                todo &= ~__ballot(mine);
+            }
+        }
+    }
+    if (COUNT) {
+        const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris), c = wave_sum(tc.spheres), d = wave_sum(tc.quads);
+        if (lane_id() == 0) {
+            if (a) atomicAdd(&stats->node_tests, (unsigned long long)a);
+            if (b) atomicAdd(&stats->tri_tests, (unsigned long long)b);
+            if (c) atomicAdd(&stats->sphere_tests, (unsigned long long)c);
+            if (d) atomicAdd(&stats->quad_tests, (unsigned long long)d);
+        }
+    }
+}
+
+// One path vertex for every path whose hit has a material of type MT: the body of
+// Camera::ray_color after the hit (src/camera.rs:286-369), in multiplicative form.
+template <int MT>
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t parity, uint32_t q) {
+    const uint32_t n = ps.ctr->shade_count[parity][q];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->shade_count[parity ^ 1u][q] = 0u;
+    const uint32_t *queue = ps.shade_queue[q];
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = queue[i];
+            const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
+            const uint32_t code = ps.hit2[slot];
+            const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+            f3 beta = mk3(b4.x, b4.y, b4.z);
+            uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
+            const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code);
+            const DevMaterial m = sc.mats[s.material];
+            if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
+                // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
+                f3 e = mk3(0.0f, 0.0f, 0.0f);
+                if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v);
+                ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
+            } else {
+                Rng rng;
+                rng.init(bp.seed_mixed, slot % bp.npix, bp.stratum_first + slot / bp.npix, __float_as_uint(ro4.w));
+                const Onb surface = make_onb(s.normal);
+                const f3 w_out = -normalize(to_local(surface, rd));
+                f3 w_in_world;
+                bool go_on = true;
+                if constexpr (MT == PTS_MAT_METAL || MT == PTS_MAT_DIELECTRIC) {
+                    // purely specular: no pdf, no roulette (camera.rs:298-313)
+                    const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
+                    const f3 attenuation = mat_eval<MT>(sc, m, w_out, w_in, s);
+                    w_in_world = to_world(surface, w_in);
+                    beta = cmul(beta, attenuation);
+                } else {
+                    // mixture of BSDF sampling and light sampling (camera.rs:317-357)
+                    f3 w_in;
+                    bool is_bsdf;
+                    if (rng.gen_bool(bp.bsdf_prob)) {
+                        w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
+                        is_bsdf = true;
+                        w_in_world = to_world(surface, w_in);
+                    } else {
+                        const f3 ls = light_sample(sc, rng, s.p);
+                        w_in = normalize(to_local(surface, ls));
+                        is_bsdf = false;
+                        w_in_world = ls;
+                    }
+                    if (!is_bsdf) depth = 2u;
+                    const float scatter_pdf = mat_pdf<MT>(m, w_out, w_in, s);
+                    const float l_pdf = light_pdf(sc, s.p, w_in_world);
+                    const float pdf = bp.bsdf_prob * scatter_pdf + (1.0f - bp.bsdf_prob) * l_pdf;
+                    const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
+                    const float cosv = fabsf(w_in.y);
+                    const f3 throughput = (bsdf * cosv) / pdf;
+                    const float weight = !is_bsdf ? 0.0f : 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
+                    if (weight != weight || rng.gen_bool(weight)) {
+                        go_on = false;  // returns Color::gray(0): contrib stays zero
+                    } else {
+                        beta = cmul(beta, throughput / (1.0f - weight));
+                    }
+                }
+                if (go_on) {
+                    depth -= 1u;
+                    if (depth == 0u) {
+                        // the next ray_color call returns zeros without tracing (camera.rs:271-273)
+                        ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
+                    } else {
+                        ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
+                        ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
+                        ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                        alive = true;
+                    }
+                }
+            }
+        }
+        if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) wave_push(alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctr->ray_count[parity ^ 1u]);
+    }
+}
+
+// `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).
+__global__ __launch_bounds__(BLOCK) void k_accumulate(const float4 *contrib, float *accum, uint32_t npix, uint32_t n_strata) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
+        float r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2];
+        for (uint32_t k = 0; k < n_strata; k++) {
+            const float4 c = contrib[(size_t)k * npix + p];
+            if (c.x != c.x || c.y != c.y || c.z != c.z) continue;
+            r += c.x;
+            g += c.y;
+            b += c.z;
+        }
+        accum[3 * p] = r;
+        accum[3 * p + 1] = g;
+        accum[3 * p + 2] = b;
+    }
+}
+
+// ColorOps::to_rgb (src/types/color.rs:36-42, :68-78) of sum / samples (camera.rs:223-225).
+__device__ __forceinline__ float linear_to_gamma(float c) {
+    if (c < 0.0031308f) return 12.92f * c;
+    return 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+}
+__global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, uint8_t *rgb, uint32_t npix, float samples) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
+        for (int c = 0; c < 3; c++) {
+            const float lin = accum[3 * p + c] / samples;
+            uint32_t v = f2u32_sat(255.999f * linear_to_gamma(lin));
+            rgb[3 * p + c] = (uint8_t)(v > 255u ? 255u : v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathState ps, uint32_t n) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float *r = rays + 8 * (size_t)i;
+        ps.ray_o[i] = make_float4(r[0], r[1], r[2], r[6]);
+        ps.ray_d[i] = make_float4(r[3], r[4], r[5], r[7]);
+        ps.ray_queue[0][i] = i;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->ray_count[0] = n;
+}
+
+// Closest hit for caller-supplied rays with their own [t_min, t_max].
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint32_t n, pt_hit *out) {
+    __shared__ uint32_t s_stack[LDS_LEVELS * BLOCK];
+    LaneStack st;
+    st.lds = s_stack + threadIdx.x;
+    st.sp = 0;
+    TravCounters tc{0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
+        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+        HitState h;
+        hit_world(sc, r, h, st, tc);
+        pt_hit o;
+        o.t = r.t_max;
+        o.u = h.u;
+        o.v = h.v;
+        if (h.code == PTD_HIT_MISS) {
+            o.prim_type = -1;
+            o.prim_id = -1;
+            o.inst_id = -1;
+            o.u = o.v = 0.0f;
+        } else {
+            const uint32_t type = h.code & 3u, inst1 = h.code >> 2;
+            o.prim_type = (int32_t)type;
+            o.inst_id = (int32_t)inst1 - 1;
+            DevSet set = sc.world;
+            if (inst1) set = sc.sets[__float_as_uint(sc.insts[7 * (size_t)(sc.world.insts.prim_first + inst1 - 1u) + 6].x)];
+            const uint32_t first = (type == PT_PRIM_TRI) ? set.tris.prim_first : ((type == PT_PRIM_SPHERE) ? set.spheres.prim_first : set.quads.prim_first);
+            o.prim_id = (int32_t)(h.prim - first);
+        }
+        out[i] = o;
+    }
+}
+
+// ============================================================================ host side
+
+struct pt_context {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // options
+    float bsdf_prob = 1.0f;
+    uint64_t max_paths = 1ull << 24;
+    bool profile = false, counters = false;
+
+    // scene
+    bool have_scene = false, have_camera = false;
+    std::vector<std::pair<void *, size_t>> scene_allocs;
+    DevScene scene{};
+    uint32_t n_queues = 0;
+    int queue_type[MAX_QUEUES];  // material type served by queue slot q
+
+    // camera + film
+    DevCamera cam{};
+    float *accum = nullptr;
+    uint8_t *rgb8 = nullptr;
+    uint32_t n_samples = 0;
+
+    // path state
+    PathState ps{};
+    std::vector<std::pair<void *, size_t>> path_allocs;
+    uint64_t path_capacity = 0;
+    DevStats *stats = nullptr;
+
+    // profiling
+    std::vector<hipEvent_t> events;
+    double extend_ms = 0, shade_ms = 0, other_ms = 0, render_ms = 0;
+    uint64_t device_bytes = 0;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(pt_context *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                      \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return fail(ctx, PT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <class T>
+static int dev_alloc(pt_context *ctx, std::vector<std::pair<void *, size_t>> &pool, T **out, size_t count) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    pool.push_back({p, bytes});
+    ctx->device_bytes += bytes;
+    *out = (T *)p;
+    return PT_OK;
+}
+template <class T>
+static int dev_upload(pt_context *ctx, std::vector<std::pair<void *, size_t>> &pool, T **out, const T *src, size_t count) {
+    int rc = dev_alloc(ctx, pool, out, count);
+    if (rc) return rc;
+    if (count) HIP_TRY(ctx, hipMemcpy(*out, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+static void free_pool(pt_context *ctx, std::vector<std::pair<void *, size_t>> &pool) {
+    for (auto &p : pool) {
+        (void)hipFree(p.first);
+        ctx->device_bytes -= p.second;
+    }
+    pool.clear();
+}
+
+static int grid_for(const pt_context *ctx, uint64_t n) {
+    uint64_t blocks = (n + BLOCK - 1) / BLOCK;
+    uint64_t cap = (uint64_t)ctx->n_cu * 8;
+    return (int)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+// Kernels whose element count lives in device memory are launched at a fixed size.
+static int grid_fixed(const pt_context *ctx, uint64_t upper_bound) {
+    uint64_t blocks = (upper_bound + BLOCK - 1) / BLOCK;
+    uint64_t cap = (uint64_t)ctx->n_cu * 5;  // 5 workgroups of 32 KB LDS fit one CU
+    return (int)std::max<uint64_t>(1, std::min(blocks, cap));
+}
+
+// The entry points below have C linkage through their declarations in ptcore.h.
+
+int pt_create(int device, pt_context **out) {
+    if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, PT_ERR_HIP, "no HIP device available: %s", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(nullptr, PT_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    pt_context *ctx = new (std::nothrow) pt_context();
+    if (!ctx) return fail(nullptr, PT_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, PT_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    void *p = nullptr;
+    if ((e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return fail(nullptr, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    ctx->stats = (DevStats *)p;
+    (void)hipMemset(ctx->stats, 0, sizeof(DevStats));
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_destroy(pt_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_pool(ctx, ctx->scene_allocs);
+    free_pool(ctx, ctx->path_allocs);
+    if (ctx->accum) (void)hipFree(ctx->accum);
+    if (ctx->rgb8) (void)hipFree(ctx->rgb8);
+    if (ctx->stats) (void)hipFree(ctx->stats);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_set_option(pt_context *ctx, int key, double value) {
+    if (!ctx) return PT_ERR_INVALID;
+    switch (key) {
+        case PT_OPT_BSDF_SAMPLE_PROBABILITY:
+            if (!(value >= 0.0 && value <= 1.0)) return fail(ctx, PT_ERR_INVALID, "bsdf sample probability must be in [0,1]");
+            ctx->bsdf_prob = (float)value;
+            return PT_OK;
+        case PT_OPT_MAX_PATHS:
+            if (!(value >= 1.0 && value <= 4.0e9)) return fail(ctx, PT_ERR_INVALID, "max paths out of range");
+            ctx->max_paths = (uint64_t)value;
+            return PT_OK;
+        case PT_OPT_PROFILE: ctx->profile = value != 0.0; return PT_OK;
+        case PT_OPT_COUNTERS: ctx->counters = value != 0.0; return PT_OK;
+    }
+    return fail(ctx, PT_ERR_INVALID, "unknown option %d", key);
+}
+
+// ---------------------------------------------------------------- scene validation + upload
+static bool buffer_ok(const pt_buffer_desc &b, uint32_t n_prims, uint32_t n_nodes) {
+    return (uint64_t)b.prim_first + b.prim_count <= n_prims && (uint64_t)b.node_first + b.node_count <= n_nodes;
+}
+
+// Checks one flat node array: children lie after their parent and inside the array, leaf
+// ranges lie inside the buffer, and no root-to-leaf path is longer than 64 nodes (the
+// traversal stack is sized from that; the reference's builder refuses deeper trees).
+static bool nodes_ok(const pt_node *nodes, uint32_t count, uint32_t prim_count, std::string &why) {
+    std::vector<std::pair<uint32_t, uint32_t>> stack;  // (node, depth)
+    stack.push_back({0u, 1u});
+    uint64_t visited = 0;
+    while (!stack.empty()) {
+        auto [i, depth] = stack.back();
+        stack.pop_back();
+        if (i >= count) { why = "child index outside the node array"; return false; }
+        if (depth > 64) { why = "BVH deeper than 64 levels"; return false; }
+        if (++visited > count) { why = "node array is not a tree"; return false; }
+        const pt_node &nd = nodes[i];
+        if (nd.b & PT_NODE_LEAF) {
+            const uint32_t size = nd.b & 0x7FFFFFFFu;
+            if (size > 0xFFFFu) { why = "leaf size above 65535"; return false; }
+            if ((uint64_t)nd.a + size > prim_count) { why = "leaf range outside its primitive buffer"; return false; }
+        } else {
+            if (nd.b > 2u) { why = "split axis above 2"; return false; }
+            if (nd.a <= i + 1 || nd.a >= count) { why = "right child must follow the left subtree"; return false; }
+            stack.push_back({nd.a, depth + 1});
+            stack.push_back({i + 1, depth + 1});
+        }
+    }
+    return true;
+}
+
+int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
+    if (!ctx || !s) return fail(ctx, PT_ERR_INVALID, "pt_upload_scene: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (s->n_sets < 2 || !s->sets) return fail(ctx, PT_ERR_INVALID, "scene needs sets[0] (objects) and sets[1] (lights)");
+    if ((s->n_tris && (!s->tri_data || !s->tri_mat)) || (s->n_spheres && (!s->spheres || !s->sphere_mat)) ||
+        (s->n_quads && (!s->quads || !s->quad_mat)) || (s->n_instances && !s->instances) || (s->n_nodes && !s->nodes) ||
+        (s->n_materials && !s->materials) || (s->n_textures && !s->textures) || (s->n_images && !s->images) ||
+        (s->n_texel_bytes && !s->texels))
+        return fail(ctx, PT_ERR_INVALID, "scene array pointer is NULL while its count is not zero");
+    std::string why;
+    for (uint32_t k = 0; k < s->n_sets; k++) {
+        const pt_primset_desc &ps = s->sets[k];
+        if (!buffer_ok(ps.tris, s->n_tris, s->n_nodes) || !buffer_ok(ps.spheres, s->n_spheres, s->n_nodes) ||
+            !buffer_ok(ps.quads, s->n_quads, s->n_nodes) || !buffer_ok(ps.instances, s->n_instances, s->n_nodes))
+            return fail(ctx, PT_ERR_INVALID, "set %u: range outside the scene arrays", k);
+        const pt_buffer_desc *bufs[4] = {&ps.tris, &ps.spheres, &ps.quads, &ps.instances};
+        for (int t = 0; t < 4; t++)
+            if (bufs[t]->node_count && !nodes_ok(s->nodes + bufs[t]->node_first, bufs[t]->node_count, bufs[t]->prim_count, why))
+                return fail(ctx, PT_ERR_INVALID, "set %u buffer %d: %s", k, t, why.c_str());
+        if (k >= 1 && ps.instances.prim_count && k != 1)
+            return fail(ctx, PT_ERR_UNSUPPORTED, "set %u: instances nested inside an instance are not supported", k);
+    }
+    for (uint32_t i = 0; i < s->n_instances; i++) {
+        const pt_instance_desc &in = s->instances[i];
+        if (in.child_set < 2 || in.child_set >= s->n_sets) return fail(ctx, PT_ERR_INVALID, "instance %u: child_set out of range", i);
+        const float *r3t = in.transform + 12, *r3i = in.inverse + 12;
+        if (r3t[0] != 0.0f || r3t[1] != 0.0f || r3t[2] != 0.0f || r3t[3] != 1.0f || r3i[0] != 0.0f || r3i[1] != 0.0f || r3i[2] != 0.0f || r3i[3] != 1.0f)
+            return fail(ctx, PT_ERR_UNSUPPORTED, "instance %u: matrix is not affine", i);
+    }
+    auto mat_ok = [&](const int32_t *m, uint32_t n) {
+        for (uint32_t i = 0; i < n; i++)
+            if (m[i] < -1 || m[i] >= (int32_t)s->n_materials) return false;
+        return true;
+    };
+    if (!mat_ok(s->tri_mat, s->n_tris) || !mat_ok(s->sphere_mat, s->n_spheres) || !mat_ok(s->quad_mat, s->n_quads))
+        return fail(ctx, PT_ERR_INVALID, "material index out of range");
+    for (uint32_t i = 0; i < s->n_textures; i++) {
+        const pts_texture &t = s->textures[i];
+        if (t.type > PTS_TEX_IMAGE) return fail(ctx, PT_ERR_INVALID, "texture %u: unknown type", i);
+        if (t.type == PTS_TEX_CHECKERED) {
+            // children must come earlier in the table: rules out cycles
+            if (t.odd < 0 || t.even < 0 || t.odd >= (int32_t)i || t.even >= (int32_t)i)
+                return fail(ctx, PT_ERR_INVALID, "texture %u: checker children must be defined before it", i);
+        }
+        if (t.type == PTS_TEX_IMAGE && t.image >= 0) {
+            if (t.image >= (int32_t)s->n_images) return fail(ctx, PT_ERR_INVALID, "texture %u: image index out of range", i);
+            const pts_image &im = s->images[t.image];
+            if (im.offset + 3ull * im.width * im.height > s->n_texel_bytes) return fail(ctx, PT_ERR_INVALID, "image %d: texels out of range", t.image);
+        }
+    }
+    bool type_present[PTS_MAT_COUNT] = {false};
+    for (uint32_t i = 0; i < s->n_materials; i++) {
+        const pt_material_desc &m = s->materials[i];
+        if (m.type >= PTS_MAT_COUNT) return fail(ctx, PT_ERR_INVALID, "material %u: unknown type", i);
+        const bool needs_tex = !(m.type == PTS_MAT_METAL || m.type == PTS_MAT_DIELECTRIC || m.type == PTS_MAT_DISNEY_CLEARCOAT);
+        if (needs_tex && (m.texture < 0 || m.texture >= (int32_t)s->n_textures)) return fail(ctx, PT_ERR_INVALID, "material %u: texture index out of range", i);
+        type_present[m.type] = true;
+    }
+
+    // ---- build device images
+    (void)hipStreamSynchronize(ctx->stream);
+    free_pool(ctx, ctx->scene_allocs);
+    ctx->have_scene = false;
+    DevScene d{};
+    std::vector<float4> hot((size_t)s->n_tris * 3), cold((size_t)s->n_tris * 6);
+    for (uint32_t i = 0; i < s->n_tris; i++) {
+        const float *t = s->tri_data + 24 * (size_t)i;  // t[row*3 + vertex]
+        const float v0x = t[0], v0y = t[3], v0z = t[6];
+        const float e1x = t[1] - v0x, e1y = t[4] - v0y, e1z = t[7] - v0z;  // position(1) - position(0)
+        const float e2x = t[2] - v0x, e2y = t[5] - v0y, e2z = t[8] - v0z;  // position(2) - position(0)
+        hot[3 * (size_t)i] = make_float4(v0x, v0y, v0z, e1x);
+        hot[3 * (size_t)i + 1] = make_float4(e1y, e1z, e2x, e2y);
+        hot[3 * (size_t)i + 2] = make_float4(e2z, 0.0f, 0.0f, 0.0f);
+        std::memcpy(&cold[6 * (size_t)i], t, 24 * sizeof(float));
+    }
+    std::vector<float4> sph(s->n_spheres), quads((size_t)s->n_quads * 4), insts((size_t)s->n_instances * 7), nodes((size_t)s->n_nodes * 2);
+    std::vector<float> qarea(s->n_quads);
+    for (uint32_t i = 0; i < s->n_spheres; i++) sph[i] = make_float4(s->spheres[4 * i], s->spheres[4 * i + 1], s->spheres[4 * i + 2], s->spheres[4 * i + 3]);
+    for (uint32_t i = 0; i < s->n_quads; i++) {
+        std::memcpy(&quads[4 * (size_t)i], s->quads + 17 * (size_t)i, 16 * sizeof(float));
+        qarea[i] = s->quads[17 * (size_t)i + 16];
+    }
+    for (uint32_t i = 0; i < s->n_instances; i++) {
+        float *o = (float *)&insts[7 * (size_t)i];
+        std::memcpy(o, s->instances[i].inverse, 12 * sizeof(float));
+        std::memcpy(o + 12, s->instances[i].transform, 12 * sizeof(float));
+        uint32_t cs = s->instances[i].child_set;
+        std::memcpy(o + 24, &cs, 4);
+        o[25] = o[26] = o[27] = 0.0f;
+    }
+    static_assert(sizeof(pt_node) == 32, "pt_node must be 32 bytes");
+    if (s->n_nodes) std::memcpy(nodes.data(), s->nodes, (size_t)s->n_nodes * 32);
+    std::vector<DevSet> sets(s->n_sets);
+    auto cvt = [](const pt_buffer_desc &b) { return DevBuffer{b.prim_first, b.prim_count, b.node_first, b.node_count}; };
+    for (uint32_t k = 0; k < s->n_sets; k++) sets[k] = DevSet{cvt(s->sets[k].tris), cvt(s->sets[k].spheres), cvt(s->sets[k].quads), cvt(s->sets[k].instances)};
+    std::vector<DevMaterial> mats(s->n_materials);
+    static_assert(sizeof(DevMaterial) == sizeof(pt_material_desc), "material layout");
+    if (s->n_materials) std::memcpy(mats.data(), s->materials, (size_t)s->n_materials * sizeof(DevMaterial));
+    ctx->n_queues = 0;
+    int slot_of_type[PTS_MAT_COUNT];
+    for (int t = 0; t < PTS_MAT_COUNT; t++) {
+        slot_of_type[t] = -1;
+        if (type_present[t]) {
+            slot_of_type[t] = (int)ctx->n_queues;
+            ctx->queue_type[ctx->n_queues++] = t;
+        }
+    }
+    std::vector<uint8_t> mat_queue(s->n_materials);
+    for (uint32_t i = 0; i < s->n_materials; i++) mat_queue[i] = (uint8_t)slot_of_type[s->materials[i].type];
+
+    int rc;
+    float4 *p4;
+#define UP4(field, vec)                                                            \
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &p4, vec.data(), vec.size()))) return rc; \
+    d.field = p4;
+    UP4(nodes, nodes) UP4(tri_hot, hot) UP4(tri_cold, cold) UP4(spheres, sph) UP4(quads, quads) UP4(insts, insts)
+#undef UP4
+    int32_t *pi;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->tri_mat, s->n_tris))) return rc;
+    d.tri_mat = pi;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->sphere_mat, s->n_spheres))) return rc;
+    d.sphere_mat = pi;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->quad_mat, s->n_quads))) return rc;
+    d.quad_mat = pi;
+    float *pf;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pf, qarea.data(), qarea.size()))) return rc;
+    d.quad_area = pf;
+    DevSet *pset;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pset, sets.data(), sets.size()))) return rc;
+    d.sets = pset;
+    DevMaterial *pm;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pm, mats.data(), mats.size()))) return rc;
+    d.mats = pm;
+    uint8_t *pu8;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pu8, mat_queue.data(), mat_queue.size()))) return rc;
+    d.mat_queue = pu8;
+    pts_texture *pt;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pt, s->textures, s->n_textures))) return rc;
+    d.textures = pt;
+    pts_image *pim;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pim, s->images, s->n_images))) return rc;
+    d.images = pim;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pu8, s->texels, (size_t)s->n_texel_bytes))) return rc;
+    d.texels = pu8;
+    d.world = sets[0];
+    d.lights = sets[1];
+    d.n_materials = s->n_materials;
+    d.n_light_total = sets[1].tris.prim_count + sets[1].spheres.prim_count + sets[1].quads.prim_count + sets[1].insts.prim_count;
+    ctx->scene = d;
+    ctx->have_scene = true;
+    // shade queues depend on which material types exist: drop path state so it is rebuilt
+    free_pool(ctx, ctx->path_allocs);
+    ctx->path_capacity = 0;
+    return PT_OK;
+}
+
+int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
+    if (!ctx || !c) return fail(ctx, PT_ERR_INVALID, "pt_set_camera: NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (c->image_width == 0 || c->image_height == 0 || (uint64_t)c->image_width * c->image_height > (1ull << 28))
+        return fail(ctx, PT_ERR_INVALID, "image size out of range");
+    if (c->sqrt_spp == 0) return fail(ctx, PT_ERR_INVALID, "sqrt_spp must be at least 1");
+    DevCamera d{};
+    d.width = c->image_width;
+    d.height = c->image_height;
+    auto v = [](const float *p) { return f3{p[0], p[1], p[2]}; };
+    d.center = v(c->center);
+    d.pixel00 = v(c->pixel00);
+    d.pixel_du = v(c->pixel_du);
+    d.pixel_dv = v(c->pixel_dv);
+    d.disk_u = v(c->defocus_disk_u);
+    d.disk_v = v(c->defocus_disk_v);
+    d.defocus_angle = c->defocus_angle;
+    d.sqrt_spp = c->sqrt_spp;
+    d.inv_sqrt_spp = c->inv_sqrt_spp;
+    d.max_depth = c->max_depth;
+    d.background = v(c->background);
+    (void)hipStreamSynchronize(ctx->stream);
+    const uint64_t npix = (uint64_t)d.width * d.height;
+    if (!ctx->have_camera || (uint64_t)ctx->cam.width * ctx->cam.height != npix) {
+        if (ctx->accum) (void)hipFree(ctx->accum);
+        if (ctx->rgb8) (void)hipFree(ctx->rgb8);
+        ctx->accum = nullptr;
+        ctx->rgb8 = nullptr;
+        hipError_t e = hipMalloc((void **)&ctx->accum, npix * 3 * sizeof(float));
+        if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc accumulator: %s", hipGetErrorString(e));
+        e = hipMalloc((void **)&ctx->rgb8, npix * 3);
+        if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc rgb8: %s", hipGetErrorString(e));
+        ctx->device_bytes += npix * 15;
+    }
+    HIP_TRY(ctx, hipMemset(ctx->accum, 0, npix * 3 * sizeof(float)));
+    ctx->n_samples = 0;
+    ctx->cam = d;
+    ctx->have_camera = true;
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------- path state
+static int ensure_paths(pt_context *ctx, uint64_t n_slots) {
+    if (n_slots <= ctx->path_capacity) return PT_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    free_pool(ctx, ctx->path_allocs);
+    ctx->path_capacity = 0;
+    PathState ps{};
+    int rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ray_o, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ray_d, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.beta, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.hit, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.hit2, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.contrib, n_slots))) return rc;
+    for (int k = 0; k < 2; k++)
+        if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ray_queue[k], n_slots))) return rc;
+    for (uint32_t q = 0; q < ctx->n_queues; q++)
+        if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.shade_queue[q], n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ctr, 1))) return rc;
+    ctx->ps = ps;
+    ctx->path_capacity = n_slots;
+    return PT_OK;
+}
+
+static hipEvent_t get_event(pt_context *ctx, size_t i) {
+    while (ctx->events.size() <= i) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->events.push_back(ev);
+    }
+    return ctx->events[i];
+}
+
+template <int MT>
+static void launch_shade(pt_context *ctx, int grid, const BatchParams &bp, uint32_t parity, uint32_t q) {
+    hipLaunchKernelGGL(k_shade<MT>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->scene, ctx->ps, bp, parity, q);
+}
+static void launch_shade_type(pt_context *ctx, int type, int grid, const BatchParams &bp, uint32_t parity, uint32_t q) {
+    switch (type) {
+        case PTS_MAT_LAMBERTIAN: launch_shade<PTS_MAT_LAMBERTIAN>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_METAL: launch_shade<PTS_MAT_METAL>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DIELECTRIC: launch_shade<PTS_MAT_DIELECTRIC>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DIFFUSE_LIGHT: launch_shade<PTS_MAT_DIFFUSE_LIGHT>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DISNEY: launch_shade<PTS_MAT_DISNEY>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DISNEY_DIFFUSE: launch_shade<PTS_MAT_DISNEY_DIFFUSE>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DISNEY_METAL: launch_shade<PTS_MAT_DISNEY_METAL>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DISNEY_GLASS: launch_shade<PTS_MAT_DISNEY_GLASS>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DISNEY_CLEARCOAT: launch_shade<PTS_MAT_DISNEY_CLEARCOAT>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_DISNEY_SHEEN: launch_shade<PTS_MAT_DISNEY_SHEEN>(ctx, grid, bp, parity, q); break;
+    }
+}
+
+static uint64_t mix64_host(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Traces one batch (strata [first, first + k)) to completion; leaves radiance in ps.contrib.
+static int run_batch(pt_context *ctx, uint32_t first, uint32_t k, uint64_t seed) {
+    const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    const uint64_t n_slots = (uint64_t)npix * k;
+    int rc = ensure_paths(ctx, n_slots);
+    if (rc) return rc;
+    BatchParams bp{mix64_host(seed), first, npix, (uint32_t)n_slots, ctx->bsdf_prob};
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->ps.ctr, 0, sizeof(DevCounters), st));
+    PathState ps = ctx->ps;
+    ps.n_slots = (uint32_t)n_slots;
+    ctx->ps = ps;
+    size_t ev = 0;
+    const bool prof = ctx->profile;
+    if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, n_slots)), dim3(BLOCK), 0, st, ctx->cam, ps, bp, ctx->stats);
+    if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+    const int grid = grid_fixed(ctx, n_slots);
+    const uint32_t depth = ctx->cam.max_depth;
+    for (uint32_t b = 0; b < depth; b++) {
+        const uint32_t parity = b & 1u;
+        if (ctx->counters)
+            hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(BLOCK), 0, st, ctx->scene, ps, parity, ctx->cam.background, ctx->stats);
+        else
+            hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(BLOCK), 0, st, ctx->scene, ps, parity, ctx->cam.background, ctx->stats);
+        if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx, ctx->queue_type[q], grid, bp, parity, q);
+        if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    if (prof) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]);
+        ctx->other_ms += ms;
+        for (uint32_t b = 0; b < depth; b++) {
+            (void)hipEventElapsedTime(&ms, ctx->events[1 + 2 * b], ctx->events[2 + 2 * b]);
+            ctx->extend_ms += ms;
+            (void)hipEventElapsedTime(&ms, ctx->events[2 + 2 * b], ctx->events[3 + 2 * b]);
+            ctx->shade_ms += ms;
+        }
+    }
+    return PT_OK;
+}
+
+static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PT_ERR_STATE, "upload a scene and set a camera before rendering");
+    const uint64_t total = (uint64_t)ctx->cam.sqrt_spp * ctx->cam.sqrt_spp;
+    if (b > e || e > total) return fail(ctx, PT_ERR_INVALID, "stratum range [%u,%u) outside [0,%llu)", b, e, (unsigned long long)total);
+    return PT_OK;
+}
+
+int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed) {
+    int rc = check_render_args(ctx, stratum_begin, stratum_end);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    auto t0 = std::chrono::steady_clock::now();
+    const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    const uint32_t per_batch = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
+    for (uint32_t s = stratum_begin; s < stratum_end;) {
+        const uint32_t k = std::min(per_batch, stratum_end - s);
+        if ((rc = run_batch(ctx, s, k, seed))) return rc;
+        size_t ev = ctx->profile ? 2 + 2 * (size_t)ctx->cam.max_depth : 0;
+        if (ctx->profile) (void)hipEventRecord(get_event(ctx, ev), ctx->stream);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->ps.contrib, ctx->accum, npix, k);
+        if (ctx->profile) {
+            (void)hipEventRecord(get_event(ctx, ev + 1), ctx->stream);
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, ctx->events[ev], ctx->events[ev + 1]);
+            ctx->other_ms += ms;
+        }
+        ctx->n_samples += k;  // `samples += 1` per pass (camera.rs:199)
+        s += k;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return PT_OK;
+}
+
+int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed, float *out) {
+    int rc = check_render_args(ctx, stratum_begin, stratum_end);
+    if (rc) return rc;
+    if (!out) return fail(ctx, PT_ERR_INVALID, "out is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    const uint32_t per_batch = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
+    std::vector<float4> host;
+    for (uint32_t s = stratum_begin; s < stratum_end;) {
+        const uint32_t k = std::min(per_batch, stratum_end - s);
+        if ((rc = run_batch(ctx, s, k, seed))) return rc;
+        const size_t n = (size_t)npix * k;
+        host.resize(n);
+        HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->ps.contrib, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float *o = out + (size_t)(s - stratum_begin) * npix * 3;
+        for (size_t i = 0; i < n; i++) {
+            o[3 * i] = host[i].x;
+            o[3 * i + 1] = host[i].y;
+            o[3 * i + 2] = host[i].z;
+        }
+        s += k;
+    }
+    return PT_OK;
+}
+
+int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *rays) {
+    int rc = check_render_args(ctx, stratum, stratum + 1);
+    if (rc) return rc;
+    if (!rays) return fail(ctx, PT_ERR_INVALID, "rays is NULL");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    float *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, (size_t)npix * 8 * sizeof(float));
+    if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    BatchParams bp{mix64_host(seed), stratum, npix, npix, ctx->bsdf_prob};
+    hipLaunchKernelGGL(k_raygen_only, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->cam, bp, d);
+    e = hipMemcpyAsync(rays, d, (size_t)npix * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_generate_rays: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "upload a scene before tracing");
+    if (n == 0) return PT_OK;
+    if (!rays || !out) return fail(ctx, PT_ERR_INVALID, "NULL ray or output array");
+    if (n > (1ull << 30)) return fail(ctx, PT_ERR_INVALID, "too many rays in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_paths(ctx, n);
+    if (rc) return rc;
+    float *d_rays = nullptr;
+    pt_hit *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, n * 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(pt_hit));
+    if (e != hipSuccess) {
+        if (d_rays) (void)hipFree(d_rays);
+        return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    hipStream_t st = ctx->stream;
+    e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, ctx->ps, (uint32_t)n);
+        hipLaunchKernelGGL(k_trace, dim3(grid_fixed(ctx, n)), dim3(BLOCK), 0, st, ctx->scene, ctx->ps, (uint32_t)n, d_out);
+        e = hipMemcpyAsync(out, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t npix = (size_t)ctx->cam.width * ctx->cam.height;
+    if (rgb_sum) HIP_TRY(ctx, hipMemcpy(rgb_sum, ctx->accum, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (n_samples) *n_samples = ctx->n_samples;
+    return PT_OK;
+}
+
+int pt_read_rgb8(pt_context *ctx, uint8_t *rgb) {
+    if (!ctx || !rgb) return fail(ctx, PT_ERR_INVALID, "NULL argument");
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    hipLaunchKernelGGL(k_tonemap, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->accum, ctx->rgb8, npix, (float)ctx->n_samples);
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->rgb8, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_reset_accum(pt_context *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemset(ctx->accum, 0, (size_t)ctx->cam.width * ctx->cam.height * 3 * sizeof(float)));
+    ctx->n_samples = 0;
+    return PT_OK;
+}
+
+int pt_copy_accum_to_device(pt_context *ctx, void *dst_device) {
+    if (!ctx || !dst_device) return fail(ctx, PT_ERR_INVALID, "NULL argument");
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(dst_device, ctx->accum, (size_t)ctx->cam.width * ctx->cam.height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_set_accum_from_device(pt_context *ctx, const void *src_device, uint32_t n_samples) {
+    if (!ctx || !src_device) return fail(ctx, PT_ERR_INVALID, "NULL argument");
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->accum, src_device, (size_t)ctx->cam.width * ctx->cam.height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_samples = n_samples;
+    return PT_OK;
+}
+
+int pt_stats_get(pt_context *ctx, pt_stats *out) {
+    if (!ctx || !out) return fail(ctx, PT_ERR_INVALID, "NULL argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DevStats ds;
+    HIP_TRY(ctx, hipMemcpy(&ds, ctx->stats, sizeof ds, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays = ds.rays_total;
+    out->paths = ds.paths_total;
+    out->extend_launches = ds.extend_nonempty;
+    out->extend_ms = ctx->extend_ms;
+    out->shade_ms = ctx->shade_ms;
+    out->other_ms = ctx->other_ms;
+    out->render_ms = ctx->render_ms;
+    out->node_tests = ds.node_tests;
+    out->tri_tests = ds.tri_tests;
+    out->sphere_tests = ds.sphere_tests;
+    out->quad_tests = ds.quad_tests;
+    out->device_bytes = ctx->device_bytes;
+    return PT_OK;
+}
+
+int pt_stats_reset(pt_context *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
+    ctx->extend_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = 0.0;
+    return PT_OK;
+}
+
