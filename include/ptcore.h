@@ -156,7 +156,8 @@ enum {
     PT_OPT_BSDF_SAMPLE_PROBABILITY = 0, /* BSDF_SAMPLE_PROBABILITY of src/camera.rs:317; default 1.0 */
     PT_OPT_MAX_PATHS = 1,               /* upper bound on paths in flight per batch; default 2^24 */
     PT_OPT_PROFILE = 2,                 /* 1: bracket kernels with HIP events, fill *_ms */
-    PT_OPT_COUNTERS = 3                 /* 1: count AABB / primitive tests (slower) */
+    PT_OPT_COUNTERS = 3,                /* 1: count AABB / primitive tests (implies the reference-order traversal) */
+    PT_OPT_TRAVERSAL = 4                /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes */
 };
 
 typedef struct pt_context pt_context;

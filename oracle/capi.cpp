@@ -196,6 +196,32 @@ void pto_trace(const pto_scene *s, const float *rays, uint64_t n, int32_t *ids, 
     }
 }
 
+
+// As pto_trace, single-threaded, and additionally returns the number of AABB tests and
+// primitive tests each ray caused: per_ray[n][2]; stack_hist[65] (may be null) = number of BVH
+// traversals whose deepest stack had k entries.
+void pto_trace_counts(const pto_scene *s, const float *rays, uint64_t n, int32_t *ids, float *tuv, uint32_t *per_ray, uint64_t *stack_hist) {
+    Counters c;
+    g_ctr = &c;
+    for (uint64_t i = 0; i < n; i++) {
+        const float *r = rays + 8 * i;
+        Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], r[7]};
+        HitRecord rec;
+        uint64_t n0 = c.nodes, p0 = c.tris + c.spheres + c.quads;
+        if (s->sc->objects.hit(ray, rec)) {
+            ids[3 * i] = rec.prim_type; ids[3 * i + 1] = rec.prim_id; ids[3 * i + 2] = rec.inst_id;
+            tuv[3 * i] = rec.t; tuv[3 * i + 1] = rec.bary_u; tuv[3 * i + 2] = rec.bary_v;
+        } else {
+            ids[3 * i] = -1; ids[3 * i + 1] = -1; ids[3 * i + 2] = -1;
+            tuv[3 * i] = ray.t_max; tuv[3 * i + 1] = 0; tuv[3 * i + 2] = 0;
+        }
+        per_ray[2 * i] = (uint32_t)(c.nodes - n0);
+        per_ray[2 * i + 1] = (uint32_t)(c.tris + c.spheres + c.quads - p0);
+    }
+    g_ctr = nullptr;
+    if (stack_hist) for (int k = 0; k < 65; k++) stack_hist[k] = c.stack_hist[k];
+}
+
 // Renders strata [begin, end) into accum (W*H*3, added to).  rgb8 / per_sample / rays / samples may be null.
 void pto_render(const pto_scene *s, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed, uint32_t threads, int iterative,
                 int tonemap_each_pass, float *accum, uint8_t *rgb8, float *per_sample, uint64_t *rays, uint32_t *samples) {

@@ -21,6 +21,8 @@ namespace oracle {
 // the bytes-per-ray model is built from.
 struct Counters {
     uint64_t nodes = 0, tris = 0, spheres = 0, quads = 0, rays = 0;
+    uint64_t max_stack = 0;            // deepest traversal stack seen
+    uint64_t stack_hist[65] = {0};     // per ray: histogram of its deepest stack
 };
 inline thread_local Counters *g_ctr = nullptr;
 
@@ -535,7 +537,7 @@ bool InnerBuffer<T>::traverse(Ray &ray, HitRecord &out, bool as_instances) const
             if (buffer[i].hit(ray, h)) { out = h; (as_instances ? out.inst_id : out.prim_id) = (int32_t)i; any = true; }
         return any;
     }
-    size_t cur = 0, top = 0;
+    size_t cur = 0, top = 0, deepest = 0;
     size_t stack[64];
     bool neg[3] = {ray.direction.x < 0.0f, ray.direction.y < 0.0f, ray.direction.z < 0.0f};
     for (;;) {
@@ -544,6 +546,7 @@ bool InnerBuffer<T>::traverse(Ray &ray, HitRecord &out, bool as_instances) const
             if (!n.is_leaf) {
                 if (neg[n.b]) { stack[top++] = cur + 1; cur = n.a; }
                 else { stack[top++] = n.a; cur += 1; }
+                if (top > deepest) deepest = top;
             } else {
                 for (size_t i = n.a; i < (size_t)n.a + n.b; i++)
                     if (buffer[i].hit(ray, h)) { out = h; (as_instances ? out.inst_id : out.prim_id) = (int32_t)i; any = true; }
@@ -554,6 +557,10 @@ bool InnerBuffer<T>::traverse(Ray &ray, HitRecord &out, bool as_instances) const
             if (top == 0) break;
             cur = stack[--top];
         }
+    }
+    if (g_ctr) {
+        if (deepest > g_ctr->max_stack) g_ctr->max_stack = deepest;
+        g_ctr->stack_hist[deepest]++;
     }
     return any;
 }

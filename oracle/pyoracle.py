@@ -45,6 +45,7 @@ def lib() -> C.CDLL:
         L.pto_primary_rays.argtypes = [C.c_void_p, C.c_void_p]
         L.pto_sample_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.pto_trace_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_render_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
@@ -155,6 +156,16 @@ class OracleScene:
         ctr = np.zeros(5, np.uint64) if counters else None
         lib().pto_trace(self.h, _p(rays), n, _p(ids), _p(tuv), _p(ctr), threads)
         return (ids, tuv, ctr) if counters else (ids, tuv)
+
+    def trace_counts(self, rays: np.ndarray):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        ids = np.zeros((n, 3), np.int32)
+        tuv = np.zeros((n, 3), np.float32)
+        per_ray = np.zeros((n, 2), np.uint32)
+        hist = np.zeros(65, np.uint64)
+        lib().pto_trace_counts(self.h, _p(rays), n, _p(ids), _p(tuv), _p(per_ray), _p(hist))
+        return ids, tuv, per_ray, hist
 
     def render(self, stratum_begin: int, stratum_end: int, seed: int = 0, threads: int = 0, iterative: bool = False,
                tonemap_each_pass: bool = False, per_sample: bool = False, accum: Optional[np.ndarray] = None,

@@ -20,7 +20,7 @@ _core: Optional[C.CDLL] = None
 _host: Optional[C.CDLL] = None
 
 PT_NODE_LEAF = 0x80000000
-(PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS) = range(4)
+(PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS, PT_OPT_TRAVERSAL) = range(5)
 
 
 class PtError(RuntimeError):

@@ -1,6 +1,7 @@
 // Device-resident scene layout (HBM) and the per-path state arrays.
 //
 //   nodes      2 x float4 per BVH node (32 B): (min.xyz, max.x) (max.yz, a, b)      — see pt_node
+//   wide       4 x float4 per interior node (64 B): left box, right box, (left ref, right ref, axis, -)
 //   tri_hot    3 x float4 per triangle (48 B, 36 used): v0, e1 = v1-v0, e2 = v2-v0   — all the intersector reads
 //   tri_cold   6 x float4 per triangle (96 B): the 8x3 attribute matrix, fetched once per path vertex
 //   spheres    1 x float4 (center, radius)
@@ -16,9 +17,17 @@
 
 namespace ptd {
 
+// One InnerPrimitiveBuffer on the device.
 struct DevBuffer {
-    uint32_t prim_first, prim_count, node_first, node_count;
+    uint32_t prim_first, prim_count;  // slice of the scene-wide primitive array of its type
+    uint32_t node_first, node_count;  // slice of `nodes` (reference order); node_count 0 = no BVH
+    uint32_t wide_first;              // first 64-byte node of this buffer in `wide`
+    uint32_t root_ref;                // reference to the root (a wide-node index or a leaf reference)
+    float rmin[3], rmax[3];           // the root's own box
 };
+// Child references inside wide nodes: an index into the buffer's wide nodes, or
+// WIDE_LEAF | count << 24 | offset (count <= 127, offset < 2^24) for a leaf.
+#define WIDE_LEAF 0x80000000u
 struct DevSet {
     DevBuffer tris, spheres, quads, insts;
 };
@@ -32,6 +41,7 @@ struct DevMaterial {  // 96 B, same field order as pt_material_desc
 
 struct DevScene {
     const float4 *nodes;
+    const float4 *wide;
     const float4 *tri_hot;
     const float4 *tri_cold;
     const int32_t *tri_mat;
@@ -86,6 +96,8 @@ struct PathState {
     uint32_t *ray_queue[2];
     uint32_t *shade_queue[MAX_QUEUES];  // capacity n_slots each, only used slots allocated
     DevCounters *ctr;
+    uint2 *overflow;           // traversal stack levels beyond LDS: [level][overflow_stride]
+    uint32_t overflow_stride;  // lanes of the widest traversal launch
     uint32_t n_slots;
 };
 

@@ -21,9 +21,8 @@
 
 namespace ptd {
 
-constexpr int BLOCK = 256;       // threads per workgroup of the traversal kernels
-constexpr int LDS_LEVELS = 32;   // stack entries per lane held in LDS (32 KB per workgroup)
-constexpr int SPILL_LEVELS = 96; // 64 levels per BVH x 2 nesting levels in the worst case
+constexpr int BLOCK = 256;      // threads per workgroup of the traversal kernels
+constexpr int LDS_LEVELS = 16;  // stack entries per lane held in LDS (8 B each: 32 KB per workgroup)
 
 struct TravRay {
     f3 o, d, inv_d;
@@ -49,18 +48,67 @@ struct TravCounters {
     uint32_t nodes, tris, spheres, quads;
 };
 
+// Per-lane traversal stack of (node reference, entry distance) pairs.
+//   - the newest entry stays in two registers (most pushes are popped right away);
+//   - the next LDS_LEVELS entries live in LDS, declared at namespace scope so that every
+//     access is a ds_read/ds_write (a pointer to LDS kept in a struct decays to a generic
+//     pointer and turns into flat_load/flat_store), laid out [level][lane] so that a wave's
+//     accesses fall on distinct banks;
+//   - deeper entries go to a global overflow array [level][launch-wide lane id]; the host
+//     sizes it from the depth of the uploaded BVHs, so it cannot be overrun.
+__shared__ uint2 g_lane_stack[LDS_LEVELS * BLOCK];
+
 struct LaneStack {
-    uint32_t *lds;  // &stack[0][threadIdx.x]; level stride = BLOCK
-    uint32_t spill[SPILL_LEVELS];
-    int sp;
-    __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < LDS_LEVELS) lds[sp * BLOCK] = v;
-        else spill[sp - LDS_LEVELS] = v;
+    uint2 *overflow;  // [levels][stride]
+    uint32_t stride;  // lanes in the launch
+    uint32_t gtid;
+    uint32_t top_ref;
+    float top_e;
+    bool has_top;
+    int sp;  // entries below the register slot
+    __device__ __forceinline__ void init(uint2 *ovf, uint32_t lanes) {
+        overflow = ovf;
+        stride = lanes;
+        gtid = blockIdx.x * BLOCK + threadIdx.x;
+        has_top = false;
+        sp = 0;
+        top_ref = 0;
+        top_e = 0.0f;
+    }
+    __device__ __forceinline__ void spill_top() {
+        const uint2 v = make_uint2(top_ref, __float_as_uint(top_e));
+        if (sp < LDS_LEVELS) g_lane_stack[sp * BLOCK + threadIdx.x] = v;
+        else overflow[(size_t)(sp - LDS_LEVELS) * stride + gtid] = v;
         sp++;
     }
-    __device__ __forceinline__ uint32_t pop() {
+    __device__ __forceinline__ void push(uint32_t ref, float e) {
+        if (has_top) spill_top();
+        top_ref = ref;
+        top_e = e;
+        has_top = true;
+    }
+    // Entries below `floor` belong to an enclosing traversal.
+    __device__ __forceinline__ bool pop(int floor, uint32_t &ref, float &e) {
+        if (has_top) {
+            ref = top_ref;
+            e = top_e;
+            has_top = false;
+            return true;
+        }
+        if (sp == floor) return false;
         sp--;
-        return sp < LDS_LEVELS ? lds[sp * BLOCK] : spill[sp - LDS_LEVELS];
+        const uint2 v = sp < LDS_LEVELS ? g_lane_stack[sp * BLOCK + threadIdx.x] : overflow[(size_t)(sp - LDS_LEVELS) * stride + gtid];
+        ref = v.x;
+        e = __uint_as_float(v.y);
+        return true;
+    }
+    // Start of a nested traversal: everything pushed so far must sit below its floor.
+    __device__ __forceinline__ int enter() {
+        if (has_top) {
+            spill_top();
+            has_top = false;
+        }
+        return sp;
     }
 };
 
@@ -82,6 +130,18 @@ __device__ __forceinline__ bool slab_test(float4 n0, float4 n1, const TravRay &r
     slab_axis(n0.x, n0.w, r.o.x, r.inv_d.x, t_min, t_max);
     slab_axis(n0.y, n1.x, r.o.y, r.inv_d.y, t_min, t_max);
     slab_axis(n0.z, n1.y, r.o.z, r.inv_d.z, t_min, t_max);
+    return !(t_max < t_min);
+}
+// The same test on a box given as six scalars; also returns the entry distance
+// E = max(ray.t_min, near planes), which does not depend on ray.t_max.  A box that passed
+// with some t_max passes with a smaller t_max' exactly when !(t_max' < E): the exit side is
+// min(t_max', X) with X = min(far planes), and the earlier pass already showed X >= E.
+__device__ __forceinline__ bool slab_test_entry(float lx, float ly, float lz, float hx, float hy, float hz, const TravRay &r, float &entry) {
+    float t_min = r.t_min, t_max = r.t_max;
+    slab_axis(lx, hx, r.o.x, r.inv_d.x, t_min, t_max);
+    slab_axis(ly, hy, r.o.y, r.inv_d.y, t_min, t_max);
+    slab_axis(lz, hz, r.o.z, r.inv_d.z, t_min, t_max);
+    entry = t_min;
     return !(t_max < t_min);
 }
 
@@ -162,53 +222,110 @@ __device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint3
     h.code = PT_PRIM_QUAD | inst_code;
 }
 
-// One InnerPrimitiveBuffer: flat-BVH traversal, or the linear scan when it has no BVH.
-template <int TYPE>
-__device__ __forceinline__ void traverse_buffer(const DevScene &sc, const DevBuffer &buf, TravRay &r, HitState &h,
-                                                uint32_t inst_code, LaneStack &st, TravCounters &tc) {
+// ---------------------------------------------------------------------------------------
+// Two traversals of one InnerPrimitiveBuffer.  Both visit leaves in the reference's order
+// and test a primitive only when the reference would.
+//
+// traverse_ref: the reference's loop verbatim over 32-byte nodes (one AABB per visit, the
+// far child is pushed untested and tested when popped).  Used when AABB / primitive tests
+// are being counted, and as the yardstick the wide form is checked against.
+//
+// traverse_wide: 64-byte nodes holding both children's boxes.  Both boxes are tested when
+// the parent is visited (nothing is intersected between that moment and the reference's own
+// test of the near child, so t_max is the same); a far child that passes is pushed with its
+// entry distance E and is dropped at pop time when t_max has shrunk below E, which is the
+// outcome of the reference's test at that moment (see slab_test_entry).  The root's own box
+// comes with the buffer descriptor.
+template <bool WIDE, class LeafFn>
+__device__ __forceinline__ void traverse(const DevScene &sc, const DevBuffer &buf, TravRay &r, LaneStack &st, TravCounters &tc,
+                                         LeafFn &&leaf) {
     if (buf.prim_count == 0) return;
-    if (buf.node_count == 0) {
-        for (uint32_t i = 0; i < buf.prim_count; i++) hit_prim<TYPE>(sc, buf.prim_first + i, r, h, inst_code, tc);
+    if (buf.node_count == 0) {  // no BVH: src/bvh.rs:726-737
+#pragma unroll 1
+        for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i);
         return;
     }
     const bool neg_x = r.d.x < 0.0f, neg_y = r.d.y < 0.0f, neg_z = r.d.z < 0.0f;
-    const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
-    const int sp0 = st.sp;
-    uint32_t cur = 0;
-    for (;;) {
-        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
-        tc.nodes++;
-        bool descend = false;
-        if (slab_test(n0, n1, r)) {
-            const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
-            if (!(b & PT_NODE_LEAF)) {
-                const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
-                if (neg) {
-                    st.push(cur + 1);
-                    cur = a;
+    const int floor = st.enter();
+    if constexpr (!WIDE) {
+        const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
+        uint32_t cur = 0;
+        for (;;) {
+            const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+            tc.nodes++;
+            bool descend = false;
+            if (slab_test(n0, n1, r)) {
+                const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
+                if (!(b & PT_NODE_LEAF)) {
+                    const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
+                    if (neg) {
+                        st.push(cur + 1, 0.0f);
+                        cur = a;
+                    } else {
+                        st.push(a, 0.0f);
+                        cur = cur + 1;
+                    }
+                    descend = true;
                 } else {
-                    st.push(a);
-                    cur = cur + 1;
+                    const uint32_t cnt = b & 0xFFFFu;
+#pragma unroll 1
+                    for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i);
                 }
-                descend = true;
-            } else {
-                const uint32_t cnt = b & 0xFFFFu;
-                for (uint32_t i = 0; i < cnt; i++) hit_prim<TYPE>(sc, buf.prim_first + a + i, r, h, inst_code, tc);
+            }
+            if (!descend) {
+                float e;
+                if (!st.pop(floor, cur, e)) break;
             }
         }
-        if (!descend) {
-            if (st.sp == sp0) break;
-            cur = st.pop();
+    } else {
+        float e;
+        if (!slab_test_entry(buf.rmin[0], buf.rmin[1], buf.rmin[2], buf.rmax[0], buf.rmax[1], buf.rmax[2], r, e)) return;
+        const float4 *wide = sc.wide + 4 * (size_t)buf.wide_first;
+        uint32_t cur = buf.root_ref;
+        for (;;) {
+            bool descend = false;
+            if (!(cur & WIDE_LEAF)) {
+                const float4 a = wide[4 * cur], b = wide[4 * cur + 1], c = wide[4 * cur + 2], d = wide[4 * cur + 3];
+                float el, er;
+                const bool hl = slab_test_entry(a.x, a.y, a.z, a.w, b.x, b.y, r, el);
+                const bool hr = slab_test_entry(b.z, b.w, c.x, c.y, c.z, c.w, r, er);
+                const uint32_t lref = __float_as_uint(d.x), rref = __float_as_uint(d.y), axis = __float_as_uint(d.z);
+                const bool neg = (axis == 0) ? neg_x : ((axis == 1) ? neg_y : neg_z);
+                const uint32_t first = neg ? rref : lref, second = neg ? lref : rref;
+                const bool hf = neg ? hr : hl, hs = neg ? hl : hr;
+                const float es = neg ? el : er;
+                if (hf) {
+                    if (hs) st.push(second, es);
+                    cur = first;
+                    descend = true;
+                } else if (hs) {
+                    cur = second;
+                    descend = true;
+                }
+            } else {
+                const uint32_t cnt = (cur >> 24) & 0x7Fu, off = cur & 0xFFFFFFu;
+#pragma unroll 1
+                for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + off + i);
+            }
+            if (!descend) {
+                bool got;
+                for (;;) {
+                    got = st.pop(floor, cur, e);
+                    if (!got || !(r.t_max < e)) break;
+                }
+                if (!got) break;
+            }
         }
     }
 }
 
 // The triangle, sphere and quad buffers of one PrimitiveBuffer, in that order.
+template <bool WIDE>
 __device__ __forceinline__ void hit_set_prims(const DevScene &sc, const DevSet &set, TravRay &r, HitState &h,
                                               uint32_t inst_code, LaneStack &st, TravCounters &tc) {
-    traverse_buffer<PT_PRIM_TRI>(sc, set.tris, r, h, inst_code, st, tc);
-    traverse_buffer<PT_PRIM_SPHERE>(sc, set.spheres, r, h, inst_code, st, tc);
-    traverse_buffer<PT_PRIM_QUAD>(sc, set.quads, r, h, inst_code, st, tc);
+    traverse<WIDE>(sc, set.tris, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_TRI>(sc, g, r, h, inst_code, tc); });
+    traverse<WIDE>(sc, set.spheres, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_SPHERE>(sc, g, r, h, inst_code, tc); });
+    traverse<WIDE>(sc, set.quads, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_QUAD>(sc, g, r, h, inst_code, tc); });
 }
 
 __device__ __forceinline__ Affine load_affine(const float4 *p) {
@@ -222,72 +339,40 @@ __device__ __forceinline__ Affine load_affine(const float4 *p) {
 
 // Instance::hit: the ray is taken into the instance's frame without renormalising the
 // direction, so t is shared between the two frames.
+template <bool WIDE>
 __device__ __forceinline__ void hit_instance(const DevScene &sc, uint32_t gi, TravRay &r, HitState &h, LaneStack &st,
                                              TravCounters &tc) {
     const float4 *ip = sc.insts + 7 * (size_t)gi;
     const Affine inv = load_affine(ip);
     const uint32_t child = __float_as_uint(ip[6].x);
     TravRay local = make_trav_ray(xf_point(inv, r.o), xf_vector(inv, r.d), r.t_min, r.t_max);
-    const uint32_t before = h.code;
-    HitState hl = h;
+    HitState hl;
     hl.code = PTD_HIT_MISS;
-    const DevSet set = sc.sets[child];
-    hit_set_prims(sc, set, local, hl, (gi - sc.world.insts.prim_first + 1u) << 2, st, tc);
+    hl.u = hl.v = 0.0f;
+    hl.prim = 0;
+    const DevSet &set = sc.sets[child];
+    hit_set_prims<WIDE>(sc, set, local, hl, (gi - sc.world.insts.prim_first + 1u) << 2, st, tc);
     if (hl.code != PTD_HIT_MISS) {
         h = hl;
         r.t_max = local.t_max;
-    } else {
-        h.code = before;
     }
 }
 
-__device__ __forceinline__ void traverse_instances(const DevScene &sc, const DevBuffer &buf, TravRay &r, HitState &h,
-                                                   LaneStack &st, TravCounters &tc) {
-    if (buf.prim_count == 0) return;
-    if (buf.node_count == 0) {
-        for (uint32_t i = 0; i < buf.prim_count; i++) hit_instance(sc, buf.prim_first + i, r, h, st, tc);
-        return;
-    }
-    const bool neg_x = r.d.x < 0.0f, neg_y = r.d.y < 0.0f, neg_z = r.d.z < 0.0f;
-    const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
-    const int sp0 = st.sp;
-    uint32_t cur = 0;
-    for (;;) {
-        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
-        tc.nodes++;
-        bool descend = false;
-        if (slab_test(n0, n1, r)) {
-            const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
-            if (!(b & PT_NODE_LEAF)) {
-                const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
-                if (neg) {
-                    st.push(cur + 1);
-                    cur = a;
-                } else {
-                    st.push(a);
-                    cur = cur + 1;
-                }
-                descend = true;
-            } else {
-                const uint32_t cnt = b & 0xFFFFu;
-                for (uint32_t i = 0; i < cnt; i++) hit_instance(sc, buf.prim_first + a + i, r, h, st, tc);
-            }
-        }
-        if (!descend) {
-            if (st.sp == sp0) break;
-            cur = st.pop();
-        }
-    }
-}
-
-// PrimitiveBuffer::hit on the world set. On return r.t_max is the hit distance (or the
-// incoming t_max on a miss) and h identifies the primitive.
-__device__ __forceinline__ void hit_world(const DevScene &sc, TravRay &r, HitState &h, LaneStack &st, TravCounters &tc) {
+// PrimitiveBuffer::hit on the world set, in two parts that run as two kernels (the second
+// only for scenes that have instances): first the triangle, sphere and quad buffers, then
+// the instance buffer, which the reference also visits last, with t_max as the first part
+// left it.  On return r.t_max is the hit distance (or the incoming t_max on a miss) and h
+// identifies the primitive.
+template <bool WIDE>
+__device__ __forceinline__ void hit_world_prims(const DevScene &sc, TravRay &r, HitState &h, LaneStack &st, TravCounters &tc) {
     h.code = PTD_HIT_MISS;
     h.u = h.v = 0.0f;
     h.prim = 0;
-    hit_set_prims(sc, sc.world, r, h, 0u, st, tc);
-    traverse_instances(sc, sc.world.insts, r, h, st, tc);
+    hit_set_prims<WIDE>(sc, sc.world, r, h, 0u, st, tc);
+}
+template <bool WIDE>
+__device__ __forceinline__ void hit_world_insts(const DevScene &sc, TravRay &r, HitState &h, LaneStack &st, TravCounters &tc) {
+    traverse<WIDE>(sc, sc.world.insts, r, st, tc, [&](uint32_t gi) { hit_instance<WIDE>(sc, gi, r, h, st, tc); });
 }
 
 }  // namespace ptd

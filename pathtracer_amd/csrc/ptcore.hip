@@ -119,12 +119,54 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
-// Closest hit for every ray of the current queue (PrimitiveBuffer::hit, src/objects.rs:191-197).
-// Missed paths and paths that hit a primitive without material finish here
-// (src/camera.rs:371, :277-283); the others are sorted by material type.
-template <bool COUNT>
+// After the closest hit is known: missed paths and paths that hit a primitive without
+// material finish here (src/camera.rs:371, :277-283); the others are appended to the queue
+// of their material type.  Every lane of the wave must call this (inactive lanes with
+// active == false).
+__device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, uint32_t parity, f3 background, bool active,
+                                         uint32_t slot, uint32_t code, uint32_t prim) {
+    uint32_t qslot = 0xFFu;
+    if (active) {
+        int32_t mat = -1;
+        if (code != PTD_HIT_MISS) {
+            const uint32_t type = code & 3u;
+            mat = (type == PT_PRIM_TRI) ? sc.tri_mat[prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[prim] : sc.quad_mat[prim]);
+        }
+        if (mat >= 0) {
+            qslot = sc.mat_queue[mat];
+        } else {
+            const float4 b = ps.beta[slot];
+            const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
+            ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+        }
+    }
+    // one pass per material queue that some lane of this wave needs
+    unsigned long long todo = __ballot(qslot != 0xFFu);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t q = (uint32_t)__shfl((int)qslot, leader, 64);
+        const bool mine = qslot == q;
+        wave_push(mine, slot, ps.shade_queue[q], &ps.ctr->shade_count[parity][q]);
+        todo &= ~__ballot(mine);
+    }
+}
+
+__device__ __forceinline__ void flush_counters(bool count, const TravCounters &tc, DevStats *stats) {
+    if (!count) return;
+    const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris), c = wave_sum(tc.spheres), d = wave_sum(tc.quads);
+    if (lane_id() == 0) {
+        if (a) atomicAdd(&stats->node_tests, (unsigned long long)a);
+        if (b) atomicAdd(&stats->tri_tests, (unsigned long long)b);
+        if (c) atomicAdd(&stats->sphere_tests, (unsigned long long)c);
+        if (d) atomicAdd(&stats->quad_tests, (unsigned long long)d);
+    }
+}
+
+// Closest hit among the world's triangles, spheres and quads for every ray of the current
+// queue (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
+// CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
+template <bool WIDE, bool COUNT, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
-    __shared__ uint32_t s_stack[LDS_LEVELS * BLOCK];
     const uint32_t n = ps.ctr->ray_count[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ps.ctr->ray_count[parity ^ 1u] = 0u;
@@ -134,58 +176,64 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
         }
     }
     LaneStack st;
-    st.lds = s_stack + threadIdx.x;
-    st.sp = 0;
+    st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
     for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
         const uint32_t i = i0 + threadIdx.x;
         const bool active = i < n;
-        uint32_t slot = 0, qslot = 0xFFu;
+        uint32_t slot = 0;
+        HitState h;
+        h.code = PTD_HIT_MISS;
+        h.prim = 0;
         if (active) {
             slot = queue[i];
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            HitState h;
-            hit_world(sc, r, h, st, tc);
+            hit_world_prims<WIDE>(sc, r, h, st, tc);
             ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
             ps.hit2[slot] = h.code;
-            {
-                int32_t mat = -1;
-                if (h.code != PTD_HIT_MISS) {
-                    const uint32_t type = h.code & 3u;
-                    mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
-                }
-                if (mat >= 0) {
-                    qslot = sc.mat_queue[mat];
-                } else {
-                    const float4 b = ps.beta[slot];
-                    const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
-                    ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
-                }
+        }
+        if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim);
+    }
+    flush_counters(COUNT, tc, stats);
+}
+
+// The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
+// continuing from the hit and t_max the first kernel left; then classification.
+template <bool WIDE, bool COUNT>
+__global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+    const uint32_t n = ps.ctr->ray_count[parity];
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    TravCounters tc{0, 0, 0, 0};
+    const uint32_t *queue = ps.ray_queue[parity];
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool active = i < n;
+        uint32_t slot = 0;
+        HitState h;
+        h.code = PTD_HIT_MISS;
+        h.prim = 0;
+        if (active) {
+            slot = queue[i];
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot], h4 = ps.hit[slot];
+            h.u = h4.y;
+            h.v = h4.z;
+            h.prim = __float_as_uint(h4.w);
+            h.code = ps.hit2[slot];
+            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, h4.x);
+            const uint32_t before = h.code;
+            const float t_before = r.t_max;
+            hit_world_insts<WIDE>(sc, r, h, st, tc);
+            if (h.code != before || r.t_max != t_before || h.prim != __float_as_uint(h4.w)) {
+                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+                ps.hit2[slot] = h.code;
             }
         }
-        {
-            // one pass per material queue that some lane of this wave needs
-            unsigned long long todo = __ballot(qslot != 0xFFu);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const uint32_t q = (uint32_t)__shfl((int)qslot, leader, 64);
-                const bool mine = qslot == q;
-                wave_push(mine, slot, ps.shade_queue[q], &ps.ctr->shade_count[parity][q]);
-                todo &= ~__ballot(mine);
-            }
-        }
+        classify(sc, ps, parity, background, active, slot, h.code, h.prim);
     }
-    if (COUNT) {
-        const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris), c = wave_sum(tc.spheres), d = wave_sum(tc.quads);
-        if (lane_id() == 0) {
-            if (a) atomicAdd(&stats->node_tests, (unsigned long long)a);
-            if (b) atomicAdd(&stats->tri_tests, (unsigned long long)b);
-            if (c) atomicAdd(&stats->sphere_tests, (unsigned long long)c);
-            if (d) atomicAdd(&stats->quad_tests, (unsigned long long)d);
-        }
-    }
+    flush_counters(COUNT, tc, stats);
 }
 
 // One path vertex for every path whose hit has a material of type MT: the body of
@@ -314,35 +362,60 @@ __global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathStat
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->ray_count[0] = n;
 }
 
-// Closest hit for caller-supplied rays with their own [t_min, t_max].
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint32_t n, pt_hit *out) {
-    __shared__ uint32_t s_stack[LDS_LEVELS * BLOCK];
+// Closest hit for caller-supplied rays with their own [t_min, t_max]: the same two parts.
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint32_t n) {
     LaneStack st;
-    st.lds = s_stack + threadIdx.x;
-    st.sp = 0;
+    st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
         TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
         HitState h;
-        hit_world(sc, r, h, st, tc);
+        hit_world_prims<WIDE>(sc, r, h, st, tc);
+        ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+        ps.hit2[i] = h.code;
+    }
+}
+template <bool WIDE>
+__global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps, uint32_t n) {
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    TravCounters tc{0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i], h4 = ps.hit[i];
+        HitState h;
+        h.u = h4.y;
+        h.v = h4.z;
+        h.prim = __float_as_uint(h4.w);
+        h.code = ps.hit2[i];
+        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, h4.x);
+        hit_world_insts<WIDE>(sc, r, h, st, tc);
+        ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+        ps.hit2[i] = h.code;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_trace_out(DevScene sc, PathState ps, uint32_t n, pt_hit *out) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float4 h4 = ps.hit[i];
+        const uint32_t code = ps.hit2[i], prim = __float_as_uint(h4.w);
         pt_hit o;
-        o.t = r.t_max;
-        o.u = h.u;
-        o.v = h.v;
-        if (h.code == PTD_HIT_MISS) {
+        o.t = h4.x;
+        o.u = h4.y;
+        o.v = h4.z;
+        if (code == PTD_HIT_MISS) {
             o.prim_type = -1;
             o.prim_id = -1;
             o.inst_id = -1;
             o.u = o.v = 0.0f;
         } else {
-            const uint32_t type = h.code & 3u, inst1 = h.code >> 2;
+            const uint32_t type = code & 3u, inst1 = code >> 2;
             o.prim_type = (int32_t)type;
             o.inst_id = (int32_t)inst1 - 1;
-            DevSet set = sc.world;
-            if (inst1) set = sc.sets[__float_as_uint(sc.insts[7 * (size_t)(sc.world.insts.prim_first + inst1 - 1u) + 6].x)];
-            const uint32_t first = (type == PT_PRIM_TRI) ? set.tris.prim_first : ((type == PT_PRIM_SPHERE) ? set.spheres.prim_first : set.quads.prim_first);
-            o.prim_id = (int32_t)(h.prim - first);
+            const DevSet *set = &sc.sets[0];
+            if (inst1) set = &sc.sets[__float_as_uint(sc.insts[7 * (size_t)(sc.world.insts.prim_first + inst1 - 1u) + 6].x)];
+            const uint32_t first = (type == PT_PRIM_TRI) ? set->tris.prim_first : ((type == PT_PRIM_SPHERE) ? set->spheres.prim_first : set->quads.prim_first);
+            o.prim_id = (int32_t)(prim - first);
         }
         out[i] = o;
     }
@@ -360,6 +433,10 @@ struct pt_context {
     float bsdf_prob = 1.0f;
     uint64_t max_paths = 1ull << 24;
     bool profile = false, counters = false;
+    bool force_ref_order = false;  // PT_OPT_TRAVERSAL = 1
+    bool wide_ok = false;          // every leaf fits the packed wide-node reference
+    uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
+    bool use_wide() const { return wide_ok && !force_ref_order; }
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -506,6 +583,7 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             return PT_OK;
         case PT_OPT_PROFILE: ctx->profile = value != 0.0; return PT_OK;
         case PT_OPT_COUNTERS: ctx->counters = value != 0.0; return PT_OK;
+        case PT_OPT_TRAVERSAL: ctx->force_ref_order = value != 0.0; return PT_OK;
     }
     return fail(ctx, PT_ERR_INVALID, "unknown option %d", key);
 }
@@ -540,6 +618,82 @@ static bool nodes_ok(const pt_node *nodes, uint32_t count, uint32_t prim_count, 
             stack.push_back({i + 1, depth + 1});
         }
     }
+    return true;
+}
+
+// Converts one reference-order node array into 64-byte two-box nodes, appended to `wide`.
+// The first nodes of the result are the top of the tree in breadth-first order (they are
+// what every ray touches); below that each subtree is laid out depth-first so that a
+// descent walks forward through memory.  Returns false when a leaf does not fit the packed
+// reference (more than 127 primitives, or an offset of 2^24 or more).
+struct WideBuild {
+    uint32_t wide_first, root_ref, depth;
+    float rmin[3], rmax[3];
+};
+static bool build_wide(const pt_node *nodes, uint32_t count, std::vector<float4> &wide, WideBuild &out) {
+    out.wide_first = (uint32_t)(wide.size() / 4);
+    std::memcpy(out.rmin, nodes[0].bmin, 12);
+    std::memcpy(out.rmax, nodes[0].bmax, 12);
+    out.depth = 1;
+    auto leaf_ref = [](const pt_node &n, uint32_t &ref) {
+        const uint32_t size = n.b & 0x7FFFFFFFu;
+        if (size > 127u || n.a >= (1u << 24)) return false;
+        ref = WIDE_LEAF | (size << 24) | n.a;
+        return true;
+    };
+    if (nodes[0].b & PT_NODE_LEAF) return leaf_ref(nodes[0], out.root_ref);
+    // 1. order of interior nodes
+    constexpr size_t TOP = 255;
+    std::vector<uint32_t> order, queue{0};
+    std::vector<uint32_t> depth_of(count, 0);
+    depth_of[0] = 1;
+    size_t qh = 0;
+    while (qh < queue.size() && order.size() < TOP) {
+        const uint32_t i = queue[qh++];
+        order.push_back(i);
+        const uint32_t kids[2] = {i + 1, nodes[i].a};
+        for (uint32_t c : kids) {
+            depth_of[c] = depth_of[i] + 1;
+            if (!(nodes[c].b & PT_NODE_LEAF)) queue.push_back(c);
+        }
+    }
+    std::vector<uint32_t> stack;
+    for (; qh < queue.size(); qh++) {  // remaining frontier: depth-first below each
+        stack.push_back(queue[qh]);
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            order.push_back(i);
+            const uint32_t l = i + 1, r = nodes[i].a;
+            depth_of[l] = depth_of[r] = depth_of[i] + 1;
+            if (!(nodes[r].b & PT_NODE_LEAF)) stack.push_back(r);
+            if (!(nodes[l].b & PT_NODE_LEAF)) stack.push_back(l);
+        }
+    }
+    std::vector<uint32_t> wide_index(count, 0xFFFFFFFFu);
+    for (size_t k = 0; k < order.size(); k++) wide_index[order[k]] = (uint32_t)k;
+    for (uint32_t i = 0; i < count; i++) out.depth = std::max(out.depth, depth_of[i]);
+    // 2. fill
+    const size_t base = wide.size();
+    wide.resize(base + 4 * order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        const uint32_t i = order[k];
+        const pt_node &L = nodes[i + 1], &R = nodes[nodes[i].a];
+        uint32_t lref, rref;
+        if (L.b & PT_NODE_LEAF) { if (!leaf_ref(L, lref)) return false; } else lref = wide_index[i + 1];
+        if (R.b & PT_NODE_LEAF) { if (!leaf_ref(R, rref)) return false; } else rref = wide_index[nodes[i].a];
+        float4 *w = &wide[base + 4 * k];
+        w[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
+        w[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
+        w[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+        float fl, fr, fa;
+        const uint32_t axis = nodes[i].b;
+        std::memcpy(&fl, &lref, 4);
+        std::memcpy(&fr, &rref, 4);
+        std::memcpy(&fa, &axis, 4);
+        w[3] = make_float4(fl, fr, fa, 0.0f);
+    }
+    out.root_ref = 0;  // the root is the first node of the breadth-first part
     return true;
 }
 
@@ -593,14 +747,21 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
             if (im.offset + 3ull * im.width * im.height > s->n_texel_bytes) return fail(ctx, PT_ERR_INVALID, "image %d: texels out of range", t.image);
         }
     }
-    bool type_present[PTS_MAT_COUNT] = {false};
     for (uint32_t i = 0; i < s->n_materials; i++) {
         const pt_material_desc &m = s->materials[i];
         if (m.type >= PTS_MAT_COUNT) return fail(ctx, PT_ERR_INVALID, "material %u: unknown type", i);
         const bool needs_tex = !(m.type == PTS_MAT_METAL || m.type == PTS_MAT_DIELECTRIC || m.type == PTS_MAT_DISNEY_CLEARCOAT);
         if (needs_tex && (m.texture < 0 || m.texture >= (int32_t)s->n_textures)) return fail(ctx, PT_ERR_INVALID, "material %u: texture index out of range", i);
-        type_present[m.type] = true;
     }
+    // a shade queue (and a shade kernel per bounce) only for material types some primitive uses
+    bool type_present[PTS_MAT_COUNT] = {false};
+    auto mark = [&](const int32_t *m, uint32_t n) {
+        for (uint32_t i = 0; i < n; i++)
+            if (m[i] >= 0) type_present[s->materials[m[i]].type] = true;
+    };
+    mark(s->tri_mat, s->n_tris);
+    mark(s->sphere_mat, s->n_spheres);
+    mark(s->quad_mat, s->n_quads);
 
     // ---- build device images
     (void)hipStreamSynchronize(ctx->stream);
@@ -636,8 +797,40 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     static_assert(sizeof(pt_node) == 32, "pt_node must be 32 bytes");
     if (s->n_nodes) std::memcpy(nodes.data(), s->nodes, (size_t)s->n_nodes * 32);
     std::vector<DevSet> sets(s->n_sets);
-    auto cvt = [](const pt_buffer_desc &b) { return DevBuffer{b.prim_first, b.prim_count, b.node_first, b.node_count}; };
-    for (uint32_t k = 0; k < s->n_sets; k++) sets[k] = DevSet{cvt(s->sets[k].tris), cvt(s->sets[k].spheres), cvt(s->sets[k].quads), cvt(s->sets[k].instances)};
+    std::vector<float4> wide;
+    bool wide_ok = true;
+    std::vector<uint32_t> set_depth(s->n_sets, 0);  // deepest BVH among the non-instance buffers of a set
+    uint32_t world_inst_depth = 0;
+    auto cvt = [&](const pt_buffer_desc &b, uint32_t &depth) {
+        DevBuffer d{};
+        d.prim_first = b.prim_first;
+        d.prim_count = b.prim_count;
+        d.node_first = b.node_first;
+        d.node_count = b.node_count;
+        depth = 0;
+        if (b.node_count) {
+            WideBuild wb{};
+            if (!build_wide(s->nodes + b.node_first, b.node_count, wide, wb)) wide_ok = false;
+            d.wide_first = wb.wide_first;
+            d.root_ref = wb.root_ref;
+            std::memcpy(d.rmin, wb.rmin, 12);
+            std::memcpy(d.rmax, wb.rmax, 12);
+            depth = wb.depth;
+        }
+        return d;
+    };
+    for (uint32_t k = 0; k < s->n_sets; k++) {
+        uint32_t dt, ds, dq, di;
+        sets[k] = DevSet{cvt(s->sets[k].tris, dt), cvt(s->sets[k].spheres, ds), cvt(s->sets[k].quads, dq), cvt(s->sets[k].instances, di)};
+        set_depth[k] = std::max(dt, std::max(ds, dq));
+        if (k == 0) world_inst_depth = di;
+    }
+    // stack entries a ray can hold at once: one per level of the BVH it is in, plus, inside
+    // an instance, those of the instance BVH above it
+    uint32_t child_depth = 0;
+    for (uint32_t k = 2; k < s->n_sets; k++) child_depth = std::max(child_depth, set_depth[k]);
+    ctx->stack_need = std::max(set_depth[0], world_inst_depth + child_depth) + 2u;
+    ctx->wide_ok = wide_ok;
     std::vector<DevMaterial> mats(s->n_materials);
     static_assert(sizeof(DevMaterial) == sizeof(pt_material_desc), "material layout");
     if (s->n_materials) std::memcpy(mats.data(), s->materials, (size_t)s->n_materials * sizeof(DevMaterial));
@@ -651,14 +844,14 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         }
     }
     std::vector<uint8_t> mat_queue(s->n_materials);
-    for (uint32_t i = 0; i < s->n_materials; i++) mat_queue[i] = (uint8_t)slot_of_type[s->materials[i].type];
+    for (uint32_t i = 0; i < s->n_materials; i++) mat_queue[i] = (uint8_t)(slot_of_type[s->materials[i].type] < 0 ? 0xFF : slot_of_type[s->materials[i].type]);
 
     int rc;
     float4 *p4;
 #define UP4(field, vec)                                                            \
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &p4, vec.data(), vec.size()))) return rc; \
     d.field = p4;
-    UP4(nodes, nodes) UP4(tri_hot, hot) UP4(tri_cold, cold) UP4(spheres, sph) UP4(quads, quads) UP4(insts, insts)
+    UP4(nodes, nodes) UP4(wide, wide) UP4(tri_hot, hot) UP4(tri_cold, cold) UP4(spheres, sph) UP4(quads, quads) UP4(insts, insts)
 #undef UP4
     int32_t *pi;
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->tri_mat, s->n_tris))) return rc;
@@ -759,6 +952,10 @@ static int ensure_paths(pt_context *ctx, uint64_t n_slots) {
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.shade_queue[q], n_slots))) return rc;
     if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ctr, 1))) return rc;
+    // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
+    ps.overflow_stride = (uint32_t)ctx->n_cu * 5u * BLOCK;
+    const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
+    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
     ctx->ps = ps;
     ctx->path_capacity = n_slots;
     return PT_OK;
@@ -771,6 +968,25 @@ static hipEvent_t get_event(pt_context *ctx, size_t i) {
         ctx->events.push_back(ev);
     }
     return ctx->events[i];
+}
+
+// One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
+static void launch_extend(pt_context *ctx, int grid, const PathState &ps, uint32_t parity) {
+    const dim3 g(grid), b(BLOCK);
+    hipStream_t st = ctx->stream;
+    const f3 bg = ctx->cam.background;
+    const bool insts = ctx->scene.world.insts.prim_count != 0;
+#define EXT(W, C, K) hipLaunchKernelGGL((k_extend<W, C, K>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
+#define EXI(W, C) hipLaunchKernelGGL((k_extend_inst<W, C>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
+    if (ctx->counters) {
+        if (insts) { EXT(false, true, false); EXI(false, true); } else EXT(false, true, true);
+    } else if (ctx->use_wide()) {
+        if (insts) { EXT(true, false, false); EXI(true, false); } else EXT(true, false, true);
+    } else {
+        if (insts) { EXT(false, false, false); EXI(false, false); } else EXT(false, false, true);
+    }
+#undef EXT
+#undef EXI
 }
 
 template <int MT>
@@ -819,10 +1035,7 @@ static int run_batch(pt_context *ctx, uint32_t first, uint32_t k, uint64_t seed)
     const uint32_t depth = ctx->cam.max_depth;
     for (uint32_t b = 0; b < depth; b++) {
         const uint32_t parity = b & 1u;
-        if (ctx->counters)
-            hipLaunchKernelGGL((k_extend<true>), dim3(grid), dim3(BLOCK), 0, st, ctx->scene, ps, parity, ctx->cam.background, ctx->stats);
-        else
-            hipLaunchKernelGGL((k_extend<false>), dim3(grid), dim3(BLOCK), 0, st, ctx->scene, ps, parity, ctx->cam.background, ctx->stats);
+        launch_extend(ctx, grid, ps, parity);
         if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
         for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx, ctx->queue_type[q], grid, bp, parity, q);
         if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
@@ -945,7 +1158,16 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, ctx->ps, (uint32_t)n);
-        hipLaunchKernelGGL(k_trace, dim3(grid_fixed(ctx, n)), dim3(BLOCK), 0, st, ctx->scene, ctx->ps, (uint32_t)n, d_out);
+        const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
+        const bool insts = ctx->scene.world.insts.prim_count != 0;
+        if (ctx->use_wide()) {
+            hipLaunchKernelGGL((k_trace<true>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL((k_trace_inst<true>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
+        } else {
+            hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL((k_trace_inst<false>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
+        }
+        hipLaunchKernelGGL(k_trace_out, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, ctx->ps, (uint32_t)n, d_out);
         e = hipMemcpyAsync(out, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
