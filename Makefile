@@ -22,7 +22,7 @@ pathtracer_amd/libpthost.so: pathtracer_amd/host/pthost.cpp $(HOST_DEP) pathtrac
 	$(CXX) $(HOSTFLAGS) -o $@ pathtracer_amd/host/pthost.cpp -Lpathtracer_amd -lptcore -Wl,-rpath,'$$ORIGIN'
 
 pathtracer_amd/ptrender: pathtracer_amd/host/ptrender.cpp $(HOST_DEP) pathtracer_amd/libpthost.so
-	$(CXX) -O2 -ffp-contract=off -std=c++17 -Wall -o $@ pathtracer_amd/host/ptrender.cpp -Lpathtracer_amd -lpthost -lptcore -Wl,-rpath,'$$ORIGIN'
+	$(CXX) -O2 -ffp-contract=off -std=c++17 -Wall -o $@ -Ipathtracer_amd/host pathtracer_amd/host/ptrender.cpp -Lpathtracer_amd -lpthost -lptcore -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle

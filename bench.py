@@ -12,7 +12,6 @@ region.  Rank 0 prints one JSON line.
 from __future__ import annotations
 
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -26,35 +25,6 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per tested item (what one ray must read at minimum)
 B_NODE, B_TRI, B_SPHERE, B_QUAD, B_RAY_IO = 32, 36, 16, 64, 32 + 16
 HBM_PEAK_GBS = 8000.0
-
-
-def stratum_ranges(total: int, world: int):
-    """Contiguous split of the s_u-major stratum list over ranks (sizes differ by at most one)."""
-    q, r = divmod(total, world)
-    out, b = [], 0
-    for k in range(world):
-        e = b + q + (1 if k < r else 0)
-        out.append((b, e))
-        b = e
-    return out
-
-
-def hip_event_ms(fn, stream=0):
-    """Times fn() with HIP events recorded on `stream` (the stream the library launches on is
-    synchronised inside pt_render, so default-stream events bracket it correctly)."""
-    hip = ctypes.CDLL("libamdhip64.so")
-    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-    hip.hipEventCreate(ctypes.byref(e0))
-    hip.hipEventCreate(ctypes.byref(e1))
-    hip.hipEventRecord(e0, ctypes.c_void_p(stream))
-    fn()
-    hip.hipEventRecord(e1, ctypes.c_void_p(stream))
-    hip.hipEventSynchronize(e1)
-    ms = ctypes.c_float(0)
-    hip.hipEventElapsedTime(ctypes.byref(ms), e0, e1)
-    hip.hipEventDestroy(e0)
-    hip.hipEventDestroy(e1)
-    return float(ms.value)
 
 
 def cpu_baseline(src, budget_s: float = 12.0):
@@ -102,6 +72,7 @@ def main():
 
     from pathtracer_amd import scenes
     from pathtracer_amd.core import PT_OPT_COUNTERS, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, HostScene, Renderer
+    from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -146,8 +117,7 @@ def main():
     for k in range(args.steps):
         step(args.warmup + k)
     r.copy_accum_to_device(accum_dev.data_ptr())
-    if world > 1:
-        dist.reduce(accum_dev, dst=0, op=dist.ReduceOp.SUM)
+    reduce_accumulator(accum_dev, dst=0)
     barrier()
     dt = time.perf_counter() - t0
     st = r.stats()

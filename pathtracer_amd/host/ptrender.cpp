@@ -1,0 +1,79 @@
+// ptrender: the reference's main() without its window (src/main.rs:62-118) — build the
+// Cornell scene with the host scene API, build the BVHs, call Camera::render on a GPU and
+// save the image (PPM instead of the reference's strat.png).
+//
+// The scene function is src/scenes/cornell.rs:18-133 written against pt:: — it shows what a
+// user of the reference's scene API finds here.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+
+#include "pthost.hpp"
+
+using namespace pt;
+
+struct Cornell {
+    static Camera build_camera(uint32_t width, uint32_t spp) {
+        return Camera(1.0f, width, 40.0f, Point3(278.0f, 278.0f, -800.0f), Point3(278.0f, 278.0f, 0.0f), 1.0f, 0.0f, spp, 16,
+                      Color(0.0f, 0.0f, 0.0f));
+    }
+    static void build_scene(PrimitiveBuffer &objects, LightBuffer &lights) {
+        MaterialRegistry materials;
+        materials.create_material("red", Lambertian::make(Color(0.65f, 0.05f, 0.05f)));
+        materials.create_material("mirror", Metal::make(Color(0.8f, 0.85f, 0.88f), 0.05f));
+        materials.create_material("white", Lambertian::make(Color(0.73f, 0.73f, 0.73f)));
+        materials.create_material("green", Lambertian::make(Color(0.12f, 0.45f, 0.15f)));
+        materials.create_material("light", Diffuse::make(Color(15.0f, 15.0f, 15.0f)));
+        materials.create_material("glass", DisneyGlass::make(Color(1.0f, 1.0f, 1.0f), 0.3f, 0.0f, 1.5f));
+
+        Quad q1(Point3(555, 0, 0), Vector3(0, 555, 0), Vector3(0, 0, 555), materials.get("green"));
+        Quad q2(Point3(0, 0, 0), Vector3(0, 555, 0), Vector3(0, 0, 555), materials.get("red"));
+        Quad q3(Point3(343, 554, 332), Vector3(-130, 0, 0), Vector3(0, 0, -105), materials.get("light"));
+        Quad q4(Point3(0, 0, 0), Vector3(555, 0, 0), Vector3(0, 0, 555), materials.get("white"));
+        Quad q5(Point3(555, 555, 555), Vector3(-555, 0, 0), Vector3(0, 0, -555), materials.get("white"));
+        Quad q6(Point3(0, 0, 555.5f), Vector3(555, 0, 0), Vector3(0, 555, 0), materials.get("white"));
+        objects.add_quad(q1);
+        objects.add_quad(q2);
+        lights.add_quad(q3);
+        objects.add_quad(q3);
+        objects.add_quad(q4);
+        objects.add_quad(q5);
+        objects.add_quad(q6);
+
+        Instance box1 = Instance::from_obj(Quad::new_box(Point3(0, 0, 0), Point3(165, 330, 165), materials.get("mirror")));
+        box1.rotate_y(15.0f * (3.14159265358979323846f / 180.0f));
+        box1.translate(Vector3(265, 0, 295));
+        PrimitiveBuffer sph;
+        sph.add_sphere(Sphere(Point3(190, 90, 190), 90.0f, materials.get("glass")));
+        objects.add_instance(box1);
+        objects.add_instance(Instance::from_obj(std::move(sph)));
+    }
+};
+
+int main(int argc, char **argv) {
+    const uint32_t width = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 768;
+    const uint32_t spp = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1024;
+    const char *out = argc > 3 ? argv[3] : "strat.ppm";
+    try {
+        std::fprintf(stderr, "Building scene...\n");
+        auto t0 = std::chrono::steady_clock::now();
+        Camera camera = Cornell::build_camera(width, spp);
+        PrimitiveBuffer objects;
+        LightBuffer lights;
+        Cornell::build_scene(objects, lights);
+        objects.build_bvh();
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "Build time: %.3f ms\nRendering...\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
+        RgbImage image;
+        camera.render(objects, lights, image, 0, 0,
+                      [](uint32_t done, uint32_t total, void *) { std::fprintf(stderr, "\r%u / %u passes", done, total); }, nullptr);
+        auto t2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "\nRender time: %.3f s\n", std::chrono::duration<double>(t2 - t1).count());
+        if (!image.save_ppm(out)) throw std::runtime_error("cannot write output image");
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "ptrender: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,249 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference renderer has no asserting tests and no golden vectors (src/materials.rs:42-66
+only prints), so these answers are derived by hand from the reference's formulas; the one
+input the reference's own test uses, refract((sqrt(.5), sqrt(.5), 0), (0,1,0), 1/1.5), is
+checked against its closed form.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from pathtracer_amd import scenes
+from pathtracer_amd.scene_src import CameraSrc, PrimSet, SceneSource
+from tests.util import bits_equal
+
+
+def _scene(fill, cam=None):
+    s = SceneSource()
+    fill(s)
+    s.camera = cam or CameraSrc(1.0, 8, 40.0, (0, 0, -5), (0, 0, 0), 1.0, 0.0, 4, 4, (0, 0, 0))
+    return po.OracleScene(s)
+
+
+def _ray(o, d, tmin=0.001, tmax=np.inf):
+    return np.array([[*o, *d, tmin, tmax]], np.float32)
+
+
+def test_refract_reference_test_input():
+    # src/materials.rs:50-53: sin_i = (1/1.5) * sqrt(.5)  ->  (-0.4714, -0.8819, 0)
+    out = po.refract((0.7071068, 0.7071068, 0.0), (0, 1, 0), 1.0 / 1.5)
+    sin_i = math.sqrt(0.5) / 1.5
+    assert np.allclose(out, [-sin_i, -math.sqrt(1 - sin_i ** 2), 0.0], atol=2e-7)
+    assert po.refract((0.99, 0.1410674, 0.0), (0, 1, 0), 1.5) is None  # total internal reflection
+
+
+def test_fresnel_o_normal_incidence_and_tir():
+    # at normal incidence both amplitudes reduce to ((1 - eta')/(1 + eta'))^2 resp. its "perp" variant of disney.rs:60
+    eta = 1.0 / 1.5
+    f = po.fresnel_o((0, 1, 0), (0, 1, 0), eta)
+    e = 1.0 / eta
+    r_para = (1 - e) / (1 + e)
+    r_perp = (e - 1) / (e + e)
+    assert abs(f - 0.5 * (r_para ** 2 + r_perp ** 2)) < 1e-7
+    assert po.fresnel_o((math.sin(1.2), math.cos(1.2), 0), (0, 1, 0), 1.5) == 1.0
+
+
+def test_onb_is_orthonormal_and_y_is_normal():
+    for n in [(0, 1, 0), (1, 0, 0), (0.95, 0.1, 0.2), (-0.3, -0.8, 0.5), (0, 0, 2)]:
+        m = po.onb(n)  # rows u, v, w
+        assert np.allclose(m @ m.T, np.eye(3), atol=1e-6)
+        assert np.allclose(m[1], np.asarray(n) / np.linalg.norm(n), atol=1e-6)
+
+
+def test_sphere_axis_aligned_hits():
+    o = _scene(lambda s: s.objects.add_sphere((0, 0, 0), 1.0, s.lambertian((.5, .5, .5))))
+    ids, tuv = o.trace(_ray((0, 0, -5), (0, 0, 1)))
+    assert ids[0].tolist() == [1, 0, -1] and tuv[0, 0] == 4.0
+    ids, tuv = o.trace(_ray((0, 0, 0), (0, 0, 2)))  # from inside: far root, direction not normalised
+    assert ids[0, 0] == 1 and tuv[0, 0] == 0.5
+    ids, _ = o.trace(_ray((0, 2, -5), (0, 0, 1)))
+    assert ids[0, 0] == -1
+    ids, tuv = o.trace(_ray((0, 0, -5), (0, 0, 1), tmax=4.0))  # root == t_max is accepted (sphere.rs:75)
+    assert ids[0, 0] == 1 and tuv[0, 0] == 4.0
+    ids, _ = o.trace(_ray((0, 0, -5), (0, 0, 1), tmax=3.9999))
+    assert ids[0, 0] == -1
+
+
+def test_triangle_hits_edges_and_ties():
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32)
+    o = _scene(lambda s: s.objects.add_triangles(tri, None, None, s.lambertian((.5, .5, .5))))
+    ids, tuv = o.trace(_ray((0.25, 0.25, -1), (0, 0, 1)))
+    assert ids[0].tolist() == [0, 0, -1] and tuv[0].tolist() == [1.0, 0.25, 0.25]
+    ids, tuv = o.trace(_ray((0.0, 0.0, -1), (0, 0, 1)))  # exactly on a vertex: u = v = 0 accepted
+    assert ids[0, 0] == 0 and tuv[0].tolist() == [1.0, 0.0, 0.0]
+    ids, tuv = o.trace(_ray((0.5, 0.5, -1), (0, 0, 1)))  # on the hypotenuse: u + v == 1 accepted
+    assert ids[0, 0] == 0
+    ids, _ = o.trace(_ray((0.51, 0.5, -1), (0, 0, 1)))
+    assert ids[0, 0] == -1
+    ids, _ = o.trace(_ray((0.25, 0.25, -1), (1, 0, 0)))  # parallel: triple == 0
+    assert ids[0, 0] == -1
+    ids, tuv = o.trace(_ray((0.25, 0.25, 1), (0, 0, -1)))  # no backface culling
+    assert ids[0, 0] == 0 and tuv[0, 0] == 1.0
+
+
+def test_two_coplanar_triangles_last_tested_wins_tie():
+    # identical triangles: both give the same t; the reference accepts t == t_max, so the later one wins
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]] * 2, np.float32)
+    o = _scene(lambda s: s.objects.add_triangles(tri, None, None, s.lambertian((.5, .5, .5))))  # no BVH: linear order
+    ids, _ = o.trace(_ray((0.25, 0.25, -1), (0, 0, 1)))
+    assert ids[0].tolist() == [0, 1, -1]
+
+
+def test_quad_hits_and_uv():
+    o = _scene(lambda s: s.objects.add_quad((0, 0, 0), (2, 0, 0), (0, 4, 0), s.lambertian((.5, .5, .5))))
+    ids, tuv = o.trace(_ray((0.5, 1.0, -3), (0, 0, 1)))
+    assert ids[0].tolist() == [2, 0, -1] and tuv[0].tolist() == [3.0, 0.25, 0.25]
+    ids, tuv = o.trace(_ray((2.0, 4.0, -3), (0, 0, 1)))  # corner: alpha = beta = 1 accepted
+    assert ids[0, 0] == 2 and tuv[0].tolist() == [3.0, 1.0, 1.0]
+    ids, _ = o.trace(_ray((2.01, 1.0, -3), (0, 0, 1)))
+    assert ids[0, 0] == -1
+    ids, _ = o.trace(_ray((0.5, 1.0, -3), (1, 0, 1e-7)))  # |denom| < 1e-6
+    assert ids[0, 0] == -1
+    q = o.quads(0)[0]
+    assert q[9:12].tolist() == [0, 0, 1] and q[15] == 0.0 and q[16] == 8.0 and np.allclose(q[12:15], [0, 0, 1 / 8])
+
+
+def test_order_triangles_spheres_quads_instances_with_shared_tmax():
+    # a quad and a sphere surface at the same t: the quad is tested later and wins the tie (objects.rs:191-197)
+    def fill(s):
+        m = s.lambertian((.5, .5, .5))
+        s.objects.add_sphere((0, 0, 1), 1.0, m)
+        s.objects.add_quad((-1, -1, 0), (2, 0, 0), (0, 2, 0), m)
+    o = _scene(fill)
+    ids, tuv = o.trace(_ray((0, 0, -2), (0, 0, 1)))
+    assert ids[0].tolist() == [2, 0, -1] and tuv[0, 0] == 2.0
+
+
+def test_instance_translate_and_rotate():
+    def fill(s):
+        from pathtracer_amd.scene_src import InstanceSrc
+        child = PrimSet()
+        child.add_sphere((0, 0, 0), 1.0, s.lambertian((.5, .5, .5)))
+        s.objects.add_instance(InstanceSrc(child).translate((0, 0, 10)))
+    o = _scene(fill)
+    ids, tuv = o.trace(_ray((0, 0, 0), (0, 0, 1)))
+    assert ids[0].tolist() == [1, 0, 0] and tuv[0, 0] == 9.0
+    m = o.instances(0)[0].reshape(2, 4, 4)
+    assert m[0, 2, 3] == 10.0 and m[1, 2, 3] == -10.0
+    assert np.allclose(m[0] @ m[1], np.eye(4))
+
+
+def test_cornell_instance_matrices():
+    o = po.OracleScene(scenes.cornell(32, 4))
+    m = o.instances(0).reshape(-1, 2, 4, 4)
+    # the builder keeps (sphere instance, box instance) in this order for the Cornell scene
+    box = m[np.argmax(np.abs(m[:, 0, 0, 3]))]
+    c, s = math.cos(math.radians(15)), math.sin(math.radians(15))
+    assert np.allclose(box[0], [[c, 0, s, 265], [0, 1, 0, 0], [-s, 0, c, 295], [0, 0, 0, 1]], atol=1e-5)
+    assert np.allclose(box[0] @ box[1], np.eye(4), atol=1e-4)
+
+
+def test_camera_constants_cornell():
+    o = po.OracleScene(scenes.cornell(256, 64))
+    k = o.camera_constants()
+    assert (k[0], k[1]) == (256, 256) and k[21] == 8 and k[22] == 0.125 and k[23] == 16
+    h = math.tan(math.radians(40) / 2)
+    vp = 2 * h
+    assert np.allclose(k[8:11], [-vp / 256, 0, 0], rtol=1e-6)  # u = vup x w points to -x for a camera looking down +z
+    assert np.allclose(k[11:14], [0, -vp / 256, 0], rtol=1e-6)
+    assert np.allclose(k[5:8], [278 + vp / 2 - vp / 512, 278 + vp / 2 - vp / 512, -799], rtol=1e-6)
+    assert CameraSrc(1.0, 768, 15.0, (0, 0, 0), (0, 0, 1), 1, 0, 10240, 50, (0, 0, 0)).sqrt_spp == 101  # floor(sqrt(10240))
+
+
+def test_srgb_quantisation():
+    rgb = np.array([[0.0, 0.0031307, 0.0031308], [0.5, 1.0, 2.0], [np.nan, -1.0, 1e30]], np.float32)
+    out = po.to_rgb8(rgb)
+    lin = lambda c: 12.92 * c if c < 0.0031308 else 1.055 * c ** (1 / 2.4) - 0.055
+    assert out[0].tolist() == [0, int(255.999 * lin(0.0031307)), int(255.999 * lin(0.0031308))]
+    assert out[1].tolist() == [int(255.999 * lin(0.5)), 255, 255]
+    assert out[2].tolist() == [0, 0, 255]  # NaN -> 0, negative -> 0 (saturating cast), overflow clamps to 255
+
+
+def test_rng_is_counter_based_and_stable():
+    a = po.rng_draws(1, 2, 3, 8)
+    b = po.rng_draws(1, 2, 3, 8)
+    assert np.array_equal(a, b) and len(set(a.tolist())) == 8
+    assert not np.array_equal(a, po.rng_draws(1, 3, 2, 8))
+    # golden values of the generator definition (SplitMix64 keyed by mix64(mix64(seed) ^ (stratum << 32 | pixel)))
+    def mix(z):
+        z &= (1 << 64) - 1
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & ((1 << 64) - 1)
+        return z ^ (z >> 31)
+    key = mix(mix(1) ^ ((3 << 32) | 2))
+    expect = [mix(key + (i + 1) * 0x9E3779B97F4A7C15) for i in range(8)]
+    assert a.tolist() == expect
+
+
+def test_texture_checker_and_image():
+    s = SceneSource()
+    img = np.arange(4 * 2 * 3, dtype=np.uint8).reshape(2, 4, 3) * 10
+    t_img = s.image(img)
+    t_none = s.image(None)
+    t_chk = s.checkered(s.solid((1, 0, 0)), s.solid((0, 1, 0)), 2.0)  # odd = red, even = green
+    s.objects.add_sphere((0, 0, 0), 1, s.lambertian_texture(t_chk))
+    s.camera = CameraSrc(1.0, 8, 40.0, (0, 0, -5), (0, 0, 0), 1.0, 0.0, 4, 4, (0, 0, 0))
+    o = po.OracleScene(s)
+    assert o.texture_value(t_chk, 0.1, 0.1).tolist() == [0, 1, 0]      # floor(.2)+floor(.2) = 0 even
+    assert o.texture_value(t_chk, 0.6, 0.1).tolist() == [1, 0, 0]      # 1 + 0 odd
+    assert o.texture_value(t_chk, -0.1, 0.1).tolist() == [1, 0, 0]     # -1 + 0 = -1, -1 % 2 = -1 != 0 -> odd
+    assert np.allclose(o.texture_value(t_img, 0.0, 1.0), img[0, 0] / 255.0)   # v flipped: v=1 is the top row
+    assert np.allclose(o.texture_value(t_img, 1.0, 0.0), img[1, 3] / 255.0)
+    assert o.texture_value(t_none, 0.0, 0.0).tolist() == [1, 1, 1] and np.allclose(o.texture_value(t_none, 1 / 64 + 1e-4, 0.0), 0.7)
+
+
+def test_lambertian_material_functions():
+    s = SceneSource()
+    m = s.lambertian((0.3, 0.6, 0.9))
+    s.objects.add_sphere((0, 0, 0), 1, m)
+    s.camera = CameraSrc(1.0, 8, 40.0, (0, 0, -5), (0, 0, 0), 1.0, 0.0, 4, 4, (0, 0, 0))
+    o = po.OracleScene(s)
+    bsdf, pdf, em = o.material_eval(m, (0, 1, 0), (0.6, 0.8, 0.0))
+    assert np.allclose(bsdf, np.array([0.3, 0.6, 0.9]) / math.pi, rtol=1e-6) and abs(pdf - 0.8 / math.pi) < 1e-7 and not em.any()
+    w, n = o.material_scatter(m, (0, 1, 0), seed=4, pixel=5, stratum=6)
+    assert n == 2 and abs(np.linalg.norm(w) - 1) < 1e-6 and w[1] >= 0
+
+
+def test_recursive_and_iterative_forms_agree():
+    for src in (scenes.cornell(24, 16), scenes.small_mixed(24, 16)):
+        o = po.OracleScene(src)
+        a = o.render(0, 4, seed=9, iterative=False, per_sample=True)
+        b = o.render(0, 4, seed=9, iterative=True, per_sample=True)
+        assert a["rays"] == b["rays"]
+        x, y = np.nan_to_num(a["per_sample"]), np.nan_to_num(b["per_sample"])
+        assert np.allclose(x, y, rtol=1e-4, atol=1e-6)
+
+
+def test_render_is_thread_count_independent_and_sums_in_stratum_order():
+    o = po.OracleScene(scenes.cornell(32, 16))
+    a = o.render(0, 6, seed=2, threads=1)["accum"]
+    b = o.render(0, 6, seed=2, threads=4)["accum"]
+    assert bits_equal(a, b)
+    c = o.render(0, 3, seed=2, threads=2)["accum"]
+    c = o.render(3, 6, seed=2, threads=2, accum=c)["accum"]
+    assert bits_equal(a, c)
+
+
+def test_light_pdf_quad_solid_angle():
+    o = po.OracleScene(scenes.cornell(16, 4))
+    # straight up from the floor centre under the 130x105 light at y = 554: pdf = d^2 / (cos * area), one light
+    pdf = o.light_pdf((278, 0, 279.5), (0, 1, 0))
+    assert abs(pdf - 554.0 ** 2 / (130 * 105)) / pdf < 1e-6
+    assert o.light_pdf((278, 0, 279.5), (1, 0, 0)) == 0.0
+
+
+def test_bvh_two_primitives_by_hand():
+    def fill(s):
+        m = s.lambertian((.5, .5, .5))
+        s.objects.add_sphere((10, 0, 0), 1.0, m)
+        s.objects.add_sphere((0, 0, 0), 1.0, m)
+        s.objects.build_bvh = True
+    o = _scene(fill)
+    bb, meta = o.bvh(0, 1)
+    # size 2: sorted by centroid on the longest axis (x), split in half -> root + two leaves; the far sphere moves second
+    assert meta.tolist() == [[0, 2, 0], [1, 0, 1], [1, 1, 1]]
+    assert o.perm(0, 1).tolist() == [1, 0]
+    assert bb[0].tolist() == [-1, -1, -1, 11, 1, 1]
