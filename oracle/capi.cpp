@@ -231,7 +231,8 @@ void pto_render(const pto_scene *s, uint32_t stratum_begin, uint32_t stratum_end
 
 // Per-ray traversal work of a whole render (all bounces), for the bytes-per-ray model:
 // counters[5] = nodes, tris, spheres, quads, rays.  Single-threaded.
-void pto_render_counters(const pto_scene *s, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed, uint32_t pixel_stride, uint64_t *counters) {
+void pto_render_counters(const pto_scene *s, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed, uint32_t pixel_stride, uint64_t *counters,
+                         uint64_t *by_bounce /* [3][64]: rays, AABB tests, largest AABB-test count of one ray; may be null */) {
     const Camera &cam = s->sc->camera;
     Counters c;
     g_ctr = &c;
@@ -247,6 +248,12 @@ void pto_render_counters(const pto_scene *s, uint32_t stratum_begin, uint32_t st
     }
     g_ctr = nullptr;
     counters[0] += c.nodes; counters[1] += c.tris; counters[2] += c.spheres; counters[3] += c.quads; counters[4] += c.rays;
+    if (by_bounce)
+        for (int k = 0; k < 64; k++) {
+            by_bounce[k] = c.depth_rays[k];
+            by_bounce[64 + k] = c.depth_nodes[k];
+            by_bounce[128 + k] = c.depth_max_nodes[k];
+        }
 }
 
 void pto_to_rgb8(const float *rgb, uint64_t npix, float divisor, uint8_t *out) {

@@ -23,6 +23,8 @@ struct Counters {
     uint64_t nodes = 0, tris = 0, spheres = 0, quads = 0, rays = 0;
     uint64_t max_stack = 0;            // deepest traversal stack seen
     uint64_t stack_hist[65] = {0};     // per ray: histogram of its deepest stack
+    // by bounce index (0 = camera ray): rays, AABB tests, and the largest AABB-test count of one ray
+    uint64_t depth_rays[64] = {0}, depth_nodes[64] = {0}, depth_max_nodes[64] = {0};
 };
 inline thread_local Counters *g_ctr = nullptr;
 

@@ -48,7 +48,7 @@ def lib() -> C.CDLL:
         L.pto_trace_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.pto_render_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p]
+        L.pto_render_counters.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_to_rgb8.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]
         L.pto_refract.restype = C.c_int
         L.pto_refract.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
@@ -183,7 +183,8 @@ class OracleScene:
 
     def render_counters(self, stratum_begin: int, stratum_end: int, seed: int = 0, pixel_stride: int = 1) -> np.ndarray:
         ctr = np.zeros(5, np.uint64)
-        lib().pto_render_counters(self.h, stratum_begin, stratum_end, seed, pixel_stride, _p(ctr))
+        self.by_bounce = np.zeros((3, 64), np.uint64)
+        lib().pto_render_counters(self.h, stratum_begin, stratum_end, seed, pixel_stride, _p(ctr), _p(self.by_bounce))
         return ctr
 
     def material_eval(self, mat: int, w_out, w_in, u=0.0, v=0.0, p=(0, 0, 0), front_face=True):

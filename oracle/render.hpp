@@ -112,7 +112,18 @@ struct Scene {
         if (rays) (*rays)++;
         if (g_ctr) g_ctr->rays++;
         HitRecord rec;
-        if (!objects.hit(ray_out, rec)) return camera.background;
+        const uint64_t nodes_before = g_ctr ? g_ctr->nodes : 0;
+        const bool any_hit = objects.hit(ray_out, rec);
+        if (g_ctr) {
+            const uint32_t bounce = camera.max_depth >= max_depth ? camera.max_depth - max_depth : 0;
+            const uint64_t n = g_ctr->nodes - nodes_before;
+            if (bounce < 64) {
+                g_ctr->depth_rays[bounce]++;
+                g_ctr->depth_nodes[bounce] += n;
+                if (n > g_ctr->depth_max_nodes[bounce]) g_ctr->depth_max_nodes[bounce] = n;
+            }
+        }
+        if (!any_hit) return camera.background;
         const Material *material = mat(rec.material);
         if (!material) return gray(0.0f);
         Color l_emitted = shading.emitted(*material, rec);

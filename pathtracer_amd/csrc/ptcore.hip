@@ -36,10 +36,39 @@ struct DevStats {
 struct BatchParams {
     uint64_t seed_mixed;
     uint32_t stratum_first;  // first stratum of this batch
+    uint32_t n_strata;       // strata in this batch
     uint32_t npix;
-    uint32_t n_slots;
+    uint32_t n_slots;        // npix * n_strata
     float bsdf_prob;
 };
+// Paths of a batch are numbered pixel-major: slot = pixel * n_strata + (stratum - stratum_first).
+// The 64 lanes of a wave then hold the strata of a few neighbouring pixels — almost the same
+// ray — and a contiguous range of slots is a band of the image with all its strata, which is
+// what the per-XCD split of the queues below relies on for L2 locality.
+__device__ __forceinline__ void slot_to_sample(const BatchParams &bp, uint32_t slot, uint32_t &pixel, uint32_t &stratum) {
+    pixel = slot / bp.n_strata;
+    stratum = bp.stratum_first + (slot - pixel * bp.n_strata);
+}
+
+// Work split of a device-counted queue of n entries over the launch: the eight groups of
+// workgroups with equal blockIdx.x % 8 (observed to share an XCD, hence an L2) each take one
+// contiguous eighth of the queue and walk it in workgroup-sized steps.  Only speed depends on
+// the placement assumption; every entry is visited exactly once whatever the placement.
+struct QueueWalk {
+    uint32_t begin, end, step;
+};
+__device__ __forceinline__ QueueWalk queue_walk(uint32_t n) {
+    const uint32_t groups = 8u;
+    const uint32_t g = blockIdx.x % groups, bi = blockIdx.x / groups;
+    const uint32_t per_group = (gridDim.x - g + groups - 1u) / groups;  // workgroups in this group
+    const uint32_t seg = ((n + groups * BLOCK - 1u) / (groups * BLOCK)) * BLOCK;
+    QueueWalk w;
+    const uint64_t b = (uint64_t)g * seg, e = b + seg;
+    w.begin = (uint32_t)(b < n ? b : n) + bi * BLOCK;
+    w.end = (uint32_t)(e < n ? e : n);
+    w.step = per_group * BLOCK;
+    return w;
+}
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -85,7 +114,8 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint3
 __global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, BatchParams bp, DevStats *stats) {
     const uint32_t n = bp.n_slots;
     for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n; slot += gridDim.x * BLOCK) {
-        const uint32_t pixel = slot % bp.npix, stratum = bp.stratum_first + slot / bp.npix;
+        uint32_t pixel, stratum;
+        slot_to_sample(bp, slot, pixel, stratum);
         Rng rng;
         rng.init(bp.seed_mixed, pixel, stratum, 0u);
         f3 o, d;
@@ -179,9 +209,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
-    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+    const QueueWalk qw = queue_walk(n);
+    for (uint32_t i0 = qw.begin; i0 < qw.end; i0 += qw.step) {
         const uint32_t i = i0 + threadIdx.x;
-        const bool active = i < n;
+        const bool active = i < qw.end;
         uint32_t slot = 0;
         HitState h;
         h.code = PTD_HIT_MISS;
@@ -208,9 +239,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
-    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+    const QueueWalk qw = queue_walk(n);
+    for (uint32_t i0 = qw.begin; i0 < qw.end; i0 += qw.step) {
         const uint32_t i = i0 + threadIdx.x;
-        const bool active = i < n;
+        const bool active = i < qw.end;
         uint32_t slot = 0;
         HitState h;
         h.code = PTD_HIT_MISS;
@@ -243,11 +275,12 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
     const uint32_t n = ps.ctr->shade_count[parity][q];
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->shade_count[parity ^ 1u][q] = 0u;
     const uint32_t *queue = ps.shade_queue[q];
-    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {
+    const QueueWalk qw = queue_walk(n);
+    for (uint32_t i0 = qw.begin; i0 < qw.end; i0 += qw.step) {
         const uint32_t i = i0 + threadIdx.x;
         bool alive = false;
         uint32_t slot = 0;
-        if (i < n) {
+        if (i < qw.end) {
             slot = queue[i];
             const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
             const uint32_t code = ps.hit2[slot];
@@ -262,8 +295,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
                 if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v);
                 ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
             } else {
+                uint32_t pixel, stratum;
+                slot_to_sample(bp, slot, pixel, stratum);
                 Rng rng;
-                rng.init(bp.seed_mixed, slot % bp.npix, bp.stratum_first + slot / bp.npix, __float_as_uint(ro4.w));
+                rng.init(bp.seed_mixed, pixel, stratum, __float_as_uint(ro4.w));
                 const Onb surface = make_onb(s.normal);
                 const f3 w_out = -normalize(to_local(surface, rd));
                 f3 w_in_world;
@@ -325,7 +360,7 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(const float4 *contrib, flo
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
         float r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2];
         for (uint32_t k = 0; k < n_strata; k++) {
-            const float4 c = contrib[(size_t)k * npix + p];
+            const float4 c = contrib[(size_t)p * n_strata + k];
             if (c.x != c.x || c.y != c.y || c.z != c.z) continue;
             r += c.x;
             g += c.y;
@@ -517,7 +552,8 @@ static int grid_for(const pt_context *ctx, uint64_t n) {
 static int grid_fixed(const pt_context *ctx, uint64_t upper_bound) {
     uint64_t blocks = (upper_bound + BLOCK - 1) / BLOCK;
     uint64_t cap = (uint64_t)ctx->n_cu * 5;  // 5 workgroups of 32 KB LDS fit one CU
-    return (int)std::max<uint64_t>(1, std::min(blocks, cap));
+    blocks = std::max<uint64_t>(1, std::min(blocks, cap));
+    return (int)((blocks + 7) / 8 * 8);  // queue_walk splits the work over eight groups of workgroups
 }
 
 // The entry points below have C linkage through their declarations in ptcore.h.
@@ -953,7 +989,7 @@ static int ensure_paths(pt_context *ctx, uint64_t n_slots) {
         if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.shade_queue[q], n_slots))) return rc;
     if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ctr, 1))) return rc;
     // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
-    ps.overflow_stride = (uint32_t)ctx->n_cu * 5u * BLOCK;
+    ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
     const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
     if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
     ctx->ps = ps;
@@ -1020,7 +1056,7 @@ static int run_batch(pt_context *ctx, uint32_t first, uint32_t k, uint64_t seed)
     const uint64_t n_slots = (uint64_t)npix * k;
     int rc = ensure_paths(ctx, n_slots);
     if (rc) return rc;
-    BatchParams bp{mix64_host(seed), first, npix, (uint32_t)n_slots, ctx->bsdf_prob};
+    BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->bsdf_prob};
     hipStream_t st = ctx->stream;
     HIP_TRY(ctx, hipMemsetAsync(ctx->ps.ctr, 0, sizeof(DevCounters), st));
     PathState ps = ctx->ps;
@@ -1108,11 +1144,12 @@ int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_
         host.resize(n);
         HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->ps.contrib, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        float *o = out + (size_t)(s - stratum_begin) * npix * 3;
-        for (size_t i = 0; i < n; i++) {
-            o[3 * i] = host[i].x;
-            o[3 * i + 1] = host[i].y;
-            o[3 * i + 2] = host[i].z;
+        for (size_t i = 0; i < n; i++) {  // slot = pixel * k + j  ->  out[stratum][pixel]
+            const size_t pixel = i / k, j = i % k;
+            float *o = out + ((size_t)(s - stratum_begin + j) * npix + pixel) * 3;
+            o[0] = host[i].x;
+            o[1] = host[i].y;
+            o[2] = host[i].z;
         }
         s += k;
     }
@@ -1128,7 +1165,7 @@ int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *ra
     float *d = nullptr;
     hipError_t e = hipMalloc((void **)&d, (size_t)npix * 8 * sizeof(float));
     if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    BatchParams bp{mix64_host(seed), stratum, npix, npix, ctx->bsdf_prob};
+    BatchParams bp{mix64_host(seed), stratum, 1u, npix, npix, ctx->bsdf_prob};
     hipLaunchKernelGGL(k_raygen_only, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->cam, bp, d);
     e = hipMemcpyAsync(rays, d, (size_t)npix * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
