@@ -32,3 +32,8 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean
+
+# Register / LDS / scratch use of every kernel (no output file).
+resources:
+	$(HIPCC) $(filter-out -shared -fPIC,$(HIPFLAGS)) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage -o /dev/null $(CORE_SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* //' | paste - - - - - -
+.PHONY: resources

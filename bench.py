@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--strata-per-step", type=int, default=16)
+    ap.add_argument("--strata-per-step", type=int, default=64)
     ap.add_argument("--scene", default="knob", choices=["knob", "cornell", "dragon_box", "interior", "next_week_like"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -88,7 +88,6 @@ def main():
     r = Renderer(host, device=local_rank)
     S = args.strata_per_step
     npix = r.npix
-    r.set_option(PT_OPT_MAX_PATHS, S * npix)
     total_strata = r.sqrt_spp * r.sqrt_spp
     need = (args.warmup + args.steps) * S
     lo, hi = stratum_ranges(total_strata, world)[rank]

@@ -83,6 +83,7 @@ constexpr int MAX_QUEUES = PTS_MAT_COUNT;
 struct DevCounters {
     uint32_t ray_count[2];                // entries in ray queue [parity]
     uint32_t shade_count[2][MAX_QUEUES];  // entries per material queue [parity][slot]
+    uint32_t walk_cursor[2][8];           // entries of ray queue [parity] handed out so far, per queue region
 };
 
 // Per-path state, indexed by slot = (stratum - batch_first_stratum) * W*H + pixel.
@@ -99,6 +100,7 @@ struct PathState {
     uint2 *overflow;           // traversal stack levels beyond LDS: [level][overflow_stride]
     uint32_t overflow_stride;  // lanes of the widest traversal launch
     uint32_t n_slots;
+    int refill_below;          // a traversing wave with fewer busy lanes than this goes back for more rays
 };
 
 }  // namespace ptd

@@ -24,6 +24,8 @@ namespace ptd {
 constexpr int BLOCK = 256;      // threads per workgroup of the traversal kernels
 constexpr int LDS_LEVELS = 16;  // stack entries per lane held in LDS (8 B each: 32 KB per workgroup)
 
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 struct TravRay {
     f3 o, d, inv_d;
     float t_min, t_max;

@@ -18,11 +18,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "dev_shade.h"
+#include "dev_walk.h"
 
 using namespace ptd;
 
@@ -69,8 +71,6 @@ __device__ __forceinline__ QueueWalk queue_walk(uint32_t n) {
     w.step = per_group * BLOCK;
     return w;
 }
-
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Appends `id` to a queue for every lane with want == true: one atomic per wave reserves
 // the range, each lane's position inside it is its rank among the wanting lanes.
@@ -228,6 +228,41 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
         if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim);
     }
     flush_counters(COUNT, tc, stats);
+}
+
+// The same step with rays drawn by the waves as their lanes fall idle (dev_walk.h); this is
+// the form used for rendering whenever the scene's leaves fit the 64-byte node layout.
+template <bool CLASSIFY>
+__global__ __launch_bounds__(BLOCK) void k_extend_walk(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+    const uint32_t n = ps.ctr->ray_count[parity];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < WALK_REGIONS) ps.ctr->walk_cursor[parity ^ 1u][threadIdx.x] = 0u;
+        if (threadIdx.x == 0) {
+            ps.ctr->ray_count[parity ^ 1u] = 0u;
+            if (n) {
+                atomicAdd(&stats->rays_total, (unsigned long long)n);
+                atomicAdd(&stats->extend_nonempty, 1ull);
+            }
+        }
+    }
+    if (n == 0u) return;
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    const uint32_t *queue = ps.ray_queue[parity];
+    walk_world_prims(
+        sc, n, ps.ctr->walk_cursor[parity], ps.refill_below, st,
+        [&](uint32_t i, uint32_t &slot, TravRay &r) {
+            slot = queue[i];
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+        },
+        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
+            if (done) {
+                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+                ps.hit2[slot] = h.code;
+            }
+            if (CLASSIFY) classify(sc, ps, parity, background, done, slot, h.code, h.prim);
+        });
 }
 
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
@@ -395,6 +430,7 @@ __global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathStat
         ps.ray_queue[0][i] = i;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->ray_count[0] = n;
+    if (blockIdx.x == 0 && threadIdx.x < WALK_REGIONS) ps.ctr->walk_cursor[0][threadIdx.x] = 0u;
 }
 
 // Closest hit for caller-supplied rays with their own [t_min, t_max]: the same two parts.
@@ -411,6 +447,23 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
         ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
         ps.hit2[i] = h.code;
     }
+}
+__global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps, uint32_t n) {
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    walk_world_prims(
+        sc, n, ps.ctr->walk_cursor[0], ps.refill_below, st,
+        [&](uint32_t i, uint32_t &slot, TravRay &r) {
+            slot = i;
+            const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
+            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+        },
+        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
+            if (done) {
+                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+                ps.hit2[slot] = h.code;
+            }
+        });
 }
 template <bool WIDE>
 __global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps, uint32_t n) {
@@ -472,6 +525,8 @@ struct pt_context {
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
+    int refill_below = 40, blocks_per_cu = 5;
+    bool trace_bounces = false, static_walk = false;
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -486,14 +541,25 @@ struct pt_context {
     uint8_t *rgb8 = nullptr;
     uint32_t n_samples = 0;
 
-    // path state
-    PathState ps{};
-    std::vector<std::pair<void *, size_t>> path_allocs;
-    uint64_t path_capacity = 0;
+    // Path state.  A render call is cut into batches of strata, and up to n_pipes batches are
+    // in flight at once, each on its own stream with its own path state: the late bounces of
+    // one batch (few rays, long dependent chains) then overlap the early bounces of another.
+    // pipes[0] runs on `stream` and also serves the first-hit and per-sample entry points.
+    struct Pipe {
+        hipStream_t stream = nullptr;
+        PathState ps{};
+        std::vector<std::pair<void *, size_t>> allocs;
+        uint64_t capacity = 0;
+        hipEvent_t accumulated = nullptr;  // recorded after the batch's k_accumulate
+        std::vector<hipEvent_t> events;    // profiling: raygen, per-bounce extend/shade, accumulate
+        uint32_t events_pending = 0;       // bounces whose events have not been read back yet
+    };
+    static constexpr int MAX_PIPES = 8;
+    Pipe pipes[MAX_PIPES];
+    int n_pipes = 4;
     DevStats *stats = nullptr;
 
     // profiling
-    std::vector<hipEvent_t> events;
     double extend_ms = 0, shade_ms = 0, other_ms = 0, render_ms = 0;
     uint64_t device_bytes = 0;
 };
@@ -551,9 +617,28 @@ static int grid_for(const pt_context *ctx, uint64_t n) {
 // Kernels whose element count lives in device memory are launched at a fixed size.
 static int grid_fixed(const pt_context *ctx, uint64_t upper_bound) {
     uint64_t blocks = (upper_bound + BLOCK - 1) / BLOCK;
-    uint64_t cap = (uint64_t)ctx->n_cu * 5;  // 5 workgroups of 32 KB LDS fit one CU
+    uint64_t cap = (uint64_t)ctx->n_cu * ctx->blocks_per_cu;  // 5 workgroups of 32 KB LDS fit one CU
     blocks = std::max<uint64_t>(1, std::min(blocks, cap));
     return (int)((blocks + 7) / 8 * 8);  // queue_walk splits the work over eight groups of workgroups
+}
+
+static void destroy_pipes(pt_context *ctx) {
+    for (auto &pp : ctx->pipes) {
+        if (pp.stream) (void)hipStreamSynchronize(pp.stream);
+        free_pool(ctx, pp.allocs);
+        pp.capacity = 0;
+        for (hipEvent_t ev : pp.events) (void)hipEventDestroy(ev);
+        pp.events.clear();
+        if (pp.accumulated) (void)hipEventDestroy(pp.accumulated);
+        pp.accumulated = nullptr;
+        if (pp.stream) (void)hipStreamDestroy(pp.stream);
+        pp.stream = nullptr;
+    }
+    ctx->stream = nullptr;
+}
+static void sync_pipes(pt_context *ctx) {
+    for (auto &pp : ctx->pipes)
+        if (pp.stream) (void)hipStreamSynchronize(pp.stream);
 }
 
 // The entry points below have C linkage through their declarations in ptcore.h.
@@ -574,15 +659,25 @@ int pt_create(int device, pt_context **out) {
     }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *v = getenv("PT_TUNE_REFILL")) ctx->refill_below = atoi(v);
+    if (const char *v = getenv("PT_TUNE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, atoi(v));
+    ctx->trace_bounces = getenv("PT_TUNE_TRACE") != nullptr;
+    ctx->static_walk = getenv("PT_TUNE_STATIC") != nullptr;
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    if (const char *v = getenv("PT_TUNE_PIPES")) ctx->n_pipes = std::min((int)pt_context::MAX_PIPES, std::max(1, atoi(v)));
+    ctx->pipes[0].stream = ctx->stream;
+    for (int i = 0; i < pt_context::MAX_PIPES && e == hipSuccess; i++) {
+        if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated, hipEventDisableTiming);
+    }
     void *p = nullptr;
-    if ((e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
-        (void)hipStreamDestroy(ctx->stream);
+    if (e != hipSuccess || (e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
+        destroy_pipes(ctx);
         delete ctx;
-        return fail(nullptr, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+        return fail(nullptr, PT_ERR_NOMEM, "stream/event/stat allocation: %s", hipGetErrorString(e));
     }
     ctx->stats = (DevStats *)p;
     (void)hipMemset(ctx->stats, 0, sizeof(DevStats));
@@ -593,14 +688,12 @@ int pt_create(int device, pt_context **out) {
 void pt_destroy(pt_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_pipes(ctx);
     free_pool(ctx, ctx->scene_allocs);
-    free_pool(ctx, ctx->path_allocs);
     if (ctx->accum) (void)hipFree(ctx->accum);
     if (ctx->rgb8) (void)hipFree(ctx->rgb8);
     if (ctx->stats) (void)hipFree(ctx->stats);
-    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(ctx->stream);
+    destroy_pipes(ctx);
     delete ctx;
 }
 
@@ -800,7 +893,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     mark(s->quad_mat, s->n_quads);
 
     // ---- build device images
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_pipes(ctx);
     free_pool(ctx, ctx->scene_allocs);
     ctx->have_scene = false;
     DevScene d{};
@@ -923,8 +1016,10 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     ctx->scene = d;
     ctx->have_scene = true;
     // shade queues depend on which material types exist: drop path state so it is rebuilt
-    free_pool(ctx, ctx->path_allocs);
-    ctx->path_capacity = 0;
+    for (auto &pp : ctx->pipes) {
+        free_pool(ctx, pp.allocs);
+        pp.capacity = 0;
+    }
     return PT_OK;
 }
 
@@ -970,54 +1065,61 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
 }
 
 // ---------------------------------------------------------------- path state
-static int ensure_paths(pt_context *ctx, uint64_t n_slots) {
-    if (n_slots <= ctx->path_capacity) return PT_OK;
-    (void)hipStreamSynchronize(ctx->stream);
-    free_pool(ctx, ctx->path_allocs);
-    ctx->path_capacity = 0;
+static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots) {
+    if (n_slots <= pp.capacity) return PT_OK;
+    (void)hipStreamSynchronize(pp.stream);
+    free_pool(ctx, pp.allocs);
+    pp.capacity = 0;
     PathState ps{};
     int rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ray_o, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ray_d, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.beta, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.hit, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.hit2, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.contrib, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_o, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_d, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.beta, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit2, n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.contrib, n_slots))) return rc;
     for (int k = 0; k < 2; k++)
-        if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ray_queue[k], n_slots))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_queue[k], n_slots))) return rc;
     for (uint32_t q = 0; q < ctx->n_queues; q++)
-        if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.shade_queue[q], n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.ctr, 1))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], n_slots))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctr, 1))) return rc;
     // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
     ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
     const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
-    if ((rc = dev_alloc(ctx, ctx->path_allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
-    ctx->ps = ps;
-    ctx->path_capacity = n_slots;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
+    ps.refill_below = ctx->refill_below;
+    pp.ps = ps;
+    pp.capacity = n_slots;
     return PT_OK;
 }
 
-static hipEvent_t get_event(pt_context *ctx, size_t i) {
-    while (ctx->events.size() <= i) {
+static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
+    while (pp.events.size() <= i) {
         hipEvent_t ev;
         if (hipEventCreate(&ev) != hipSuccess) return nullptr;
-        ctx->events.push_back(ev);
+        pp.events.push_back(ev);
     }
-    return ctx->events[i];
+    return pp.events[i];
 }
 
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
-static void launch_extend(pt_context *ctx, int grid, const PathState &ps, uint32_t parity) {
+static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t parity) {
     const dim3 g(grid), b(BLOCK);
-    hipStream_t st = ctx->stream;
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
 #define EXT(W, C, K) hipLaunchKernelGGL((k_extend<W, C, K>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
 #define EXI(W, C) hipLaunchKernelGGL((k_extend_inst<W, C>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
     if (ctx->counters) {
         if (insts) { EXT(false, true, false); EXI(false, true); } else EXT(false, true, true);
-    } else if (ctx->use_wide()) {
+    } else if (ctx->use_wide() && ctx->static_walk) {
         if (insts) { EXT(true, false, false); EXI(true, false); } else EXT(true, false, true);
+    } else if (ctx->use_wide()) {
+        if (insts) {
+            hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
+            EXI(true, false);
+        } else {
+            hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
+        }
     } else {
         if (insts) { EXT(false, false, false); EXI(false, false); } else EXT(false, false, true);
     }
@@ -1025,22 +1127,30 @@ static void launch_extend(pt_context *ctx, int grid, const PathState &ps, uint32
 #undef EXI
 }
 
+struct ShadeLaunch {
+    pt_context *ctx;
+    hipStream_t st;
+    const PathState *ps;
+    int grid;
+    const BatchParams *bp;
+    uint32_t parity, q;
+};
 template <int MT>
-static void launch_shade(pt_context *ctx, int grid, const BatchParams &bp, uint32_t parity, uint32_t q) {
-    hipLaunchKernelGGL(k_shade<MT>, dim3(grid), dim3(BLOCK), 0, ctx->stream, ctx->scene, ctx->ps, bp, parity, q);
+static void launch_shade(const ShadeLaunch &l) {
+    hipLaunchKernelGGL(k_shade<MT>, dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.parity, l.q);
 }
-static void launch_shade_type(pt_context *ctx, int type, int grid, const BatchParams &bp, uint32_t parity, uint32_t q) {
+static void launch_shade_type(int type, const ShadeLaunch &l) {
     switch (type) {
-        case PTS_MAT_LAMBERTIAN: launch_shade<PTS_MAT_LAMBERTIAN>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_METAL: launch_shade<PTS_MAT_METAL>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DIELECTRIC: launch_shade<PTS_MAT_DIELECTRIC>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DIFFUSE_LIGHT: launch_shade<PTS_MAT_DIFFUSE_LIGHT>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DISNEY: launch_shade<PTS_MAT_DISNEY>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DISNEY_DIFFUSE: launch_shade<PTS_MAT_DISNEY_DIFFUSE>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DISNEY_METAL: launch_shade<PTS_MAT_DISNEY_METAL>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DISNEY_GLASS: launch_shade<PTS_MAT_DISNEY_GLASS>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DISNEY_CLEARCOAT: launch_shade<PTS_MAT_DISNEY_CLEARCOAT>(ctx, grid, bp, parity, q); break;
-        case PTS_MAT_DISNEY_SHEEN: launch_shade<PTS_MAT_DISNEY_SHEEN>(ctx, grid, bp, parity, q); break;
+        case PTS_MAT_LAMBERTIAN: launch_shade<PTS_MAT_LAMBERTIAN>(l); break;
+        case PTS_MAT_METAL: launch_shade<PTS_MAT_METAL>(l); break;
+        case PTS_MAT_DIELECTRIC: launch_shade<PTS_MAT_DIELECTRIC>(l); break;
+        case PTS_MAT_DIFFUSE_LIGHT: launch_shade<PTS_MAT_DIFFUSE_LIGHT>(l); break;
+        case PTS_MAT_DISNEY: launch_shade<PTS_MAT_DISNEY>(l); break;
+        case PTS_MAT_DISNEY_DIFFUSE: launch_shade<PTS_MAT_DISNEY_DIFFUSE>(l); break;
+        case PTS_MAT_DISNEY_METAL: launch_shade<PTS_MAT_DISNEY_METAL>(l); break;
+        case PTS_MAT_DISNEY_GLASS: launch_shade<PTS_MAT_DISNEY_GLASS>(l); break;
+        case PTS_MAT_DISNEY_CLEARCOAT: launch_shade<PTS_MAT_DISNEY_CLEARCOAT>(l); break;
+        case PTS_MAT_DISNEY_SHEEN: launch_shade<PTS_MAT_DISNEY_SHEEN>(l); break;
     }
 }
 
@@ -1050,45 +1160,56 @@ static uint64_t mix64_host(uint64_t z) {
     return z ^ (z >> 31);
 }
 
-// Traces one batch (strata [first, first + k)) to completion; leaves radiance in ps.contrib.
-static int run_batch(pt_context *ctx, uint32_t first, uint32_t k, uint64_t seed) {
+// Reads back the event timings a pipe still holds (profiling only); waits for that batch.
+static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp) {
+    if (!pp.events_pending) return;
+    const uint32_t depth = pp.events_pending;
+    pp.events_pending = 0;
+    const size_t last = 3 + 2 * (size_t)depth;
+    if (pp.events.size() <= last || hipEventSynchronize(pp.events[last]) != hipSuccess) return;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, pp.events[0], pp.events[1]);
+    ctx->other_ms += ms;
+    for (uint32_t b = 0; b < depth; b++) {
+        (void)hipEventElapsedTime(&ms, pp.events[1 + 2 * b], pp.events[2 + 2 * b]);
+        ctx->extend_ms += ms;
+        if (ctx->trace_bounces && b < 12) fprintf(stderr, "bounce %u extend %.3f ms\n", b, ms);
+        (void)hipEventElapsedTime(&ms, pp.events[2 + 2 * b], pp.events[3 + 2 * b]);
+        ctx->shade_ms += ms;
+    }
+    (void)hipEventElapsedTime(&ms, pp.events[last - 1], pp.events[last]);
+    ctx->other_ms += ms;
+}
+
+// Enqueues one batch (strata [first, first + k)) on a pipe: every bounce, no host wait.
+// Radiance is left in the pipe's ps.contrib.
+static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint32_t k, uint64_t seed) {
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
     const uint64_t n_slots = (uint64_t)npix * k;
-    int rc = ensure_paths(ctx, n_slots);
+    harvest_profile(ctx, pp);
+    int rc = ensure_paths(ctx, pp, n_slots);
     if (rc) return rc;
     BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->bsdf_prob};
-    hipStream_t st = ctx->stream;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->ps.ctr, 0, sizeof(DevCounters), st));
-    PathState ps = ctx->ps;
-    ps.n_slots = (uint32_t)n_slots;
-    ctx->ps = ps;
+    hipStream_t st = pp.stream;
+    HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctr, 0, sizeof(DevCounters), st));
+    pp.ps.n_slots = (uint32_t)n_slots;
+    pp.ps.refill_below = ctx->refill_below;
+    const PathState ps = pp.ps;
     size_t ev = 0;
     const bool prof = ctx->profile;
-    if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+    if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, n_slots)), dim3(BLOCK), 0, st, ctx->cam, ps, bp, ctx->stats);
-    if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+    if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     const int grid = grid_fixed(ctx, n_slots);
     const uint32_t depth = ctx->cam.max_depth;
     for (uint32_t b = 0; b < depth; b++) {
         const uint32_t parity = b & 1u;
-        launch_extend(ctx, grid, ps, parity);
-        if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
-        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx, ctx->queue_type[q], grid, bp, parity, q);
-        if (prof) (void)hipEventRecord(get_event(ctx, ev++), st);
+        launch_extend(ctx, st, grid, ps, parity);
+        if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
+        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid, &bp, parity, q});
+        if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
     HIP_TRY(ctx, hipGetLastError());
-    if (prof) {
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->events[0], ctx->events[1]);
-        ctx->other_ms += ms;
-        for (uint32_t b = 0; b < depth; b++) {
-            (void)hipEventElapsedTime(&ms, ctx->events[1 + 2 * b], ctx->events[2 + 2 * b]);
-            ctx->extend_ms += ms;
-            (void)hipEventElapsedTime(&ms, ctx->events[2 + 2 * b], ctx->events[3 + 2 * b]);
-            ctx->shade_ms += ms;
-        }
-    }
     return PT_OK;
 }
 
@@ -1106,24 +1227,38 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
-    const uint32_t per_batch = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
-    for (uint32_t s = stratum_begin; s < stratum_end;) {
+    // Batch size: at most max_paths paths, and small enough that the request keeps every
+    // pipe busy, but not below about a million paths (a launch has to fill the chip).
+    const uint32_t total = stratum_end - stratum_begin;
+    const uint32_t cap = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
+    const uint32_t floor_k = (uint32_t)std::max<uint64_t>(1, ((1ull << 20) + npix - 1) / npix);
+    const uint32_t even = (total + (uint32_t)ctx->n_pipes - 1) / (uint32_t)ctx->n_pipes;
+    const uint32_t per_batch = std::min(cap, std::max(even, floor_k));
+    // k_accumulate of batch i runs on batch i's stream after batch i-1's k_accumulate, so each
+    // pixel receives its samples in stratum order whatever the overlap (camera.rs:212-217).
+    hipEvent_t prev_accumulated = nullptr;
+    uint32_t batch = 0;
+    for (uint32_t s = stratum_begin; s < stratum_end; batch++) {
+        pt_context::Pipe &pp = ctx->pipes[batch % (uint32_t)ctx->n_pipes];
         const uint32_t k = std::min(per_batch, stratum_end - s);
-        if ((rc = run_batch(ctx, s, k, seed))) return rc;
-        size_t ev = ctx->profile ? 2 + 2 * (size_t)ctx->cam.max_depth : 0;
-        if (ctx->profile) (void)hipEventRecord(get_event(ctx, ev), ctx->stream);
-        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->ps.contrib, ctx->accum, npix, k);
+        if ((rc = run_batch(ctx, pp, s, k, seed))) return rc;
+        if (prev_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(pp.stream, prev_accumulated, 0));
+        const size_t ev = 2 + 2 * (size_t)ctx->cam.max_depth;
+        if (ctx->profile) (void)hipEventRecord(get_event(pp, ev), pp.stream);
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, pp.stream, pp.ps.contrib, ctx->accum, npix, k);
         if (ctx->profile) {
-            (void)hipEventRecord(get_event(ctx, ev + 1), ctx->stream);
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, ctx->events[ev], ctx->events[ev + 1]);
-            ctx->other_ms += ms;
+            (void)hipEventRecord(get_event(pp, ev + 1), pp.stream);
+            pp.events_pending = ctx->cam.max_depth;
         }
+        HIP_TRY(ctx, hipEventRecord(pp.accumulated, pp.stream));
+        prev_accumulated = pp.accumulated;
         ctx->n_samples += k;  // `samples += 1` per pass (camera.rs:199)
         s += k;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < ctx->n_pipes; i++) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->pipes[i].stream));
+        harvest_profile(ctx, ctx->pipes[i]);
+    }
     HIP_TRY(ctx, hipGetLastError());
     ctx->render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return PT_OK;
@@ -1136,14 +1271,21 @@ int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
     const uint32_t per_batch = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
+    pt_context::Pipe &pp = ctx->pipes[0];
+    const bool prof = ctx->profile;
+    ctx->profile = false;
     std::vector<float4> host;
     for (uint32_t s = stratum_begin; s < stratum_end;) {
         const uint32_t k = std::min(per_batch, stratum_end - s);
-        if ((rc = run_batch(ctx, s, k, seed))) return rc;
+        if ((rc = run_batch(ctx, pp, s, k, seed))) break;
         const size_t n = (size_t)npix * k;
         host.resize(n);
-        HIP_TRY(ctx, hipMemcpyAsync(host.data(), ctx->ps.contrib, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        hipError_t e = hipMemcpyAsync(host.data(), pp.ps.contrib, n * sizeof(float4), hipMemcpyDeviceToHost, pp.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(pp.stream);
+        if (e != hipSuccess) {
+            rc = fail(ctx, PT_ERR_HIP, "pt_render_samples: %s", hipGetErrorString(e));
+            break;
+        }
         for (size_t i = 0; i < n; i++) {  // slot = pixel * k + j  ->  out[stratum][pixel]
             const size_t pixel = i / k, j = i % k;
             float *o = out + ((size_t)(s - stratum_begin + j) * npix + pixel) * 3;
@@ -1153,7 +1295,8 @@ int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_
         }
         s += k;
     }
-    return PT_OK;
+    ctx->profile = prof;
+    return rc;
 }
 
 int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *rays) {
@@ -1181,7 +1324,8 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     if (!rays || !out) return fail(ctx, PT_ERR_INVALID, "NULL ray or output array");
     if (n > (1ull << 30)) return fail(ctx, PT_ERR_INVALID, "too many rays in one call");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_paths(ctx, n);
+    pt_context::Pipe &pp = ctx->pipes[0];
+    int rc = ensure_paths(ctx, pp, n);
     if (rc) return rc;
     float *d_rays = nullptr;
     pt_hit *d_out = nullptr;
@@ -1194,17 +1338,17 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     hipStream_t st = ctx->stream;
     e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, ctx->ps, (uint32_t)n);
+        hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, pp.ps, (uint32_t)n);
         const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
         const bool insts = ctx->scene.world.insts.prim_count != 0;
         if (ctx->use_wide()) {
-            hipLaunchKernelGGL((k_trace<true>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
-            if (insts) hipLaunchKernelGGL((k_trace_inst<true>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
+            hipLaunchKernelGGL(k_trace_walk, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL((k_trace_inst<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         } else {
-            hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
-            if (insts) hipLaunchKernelGGL((k_trace_inst<false>), g, b, 0, st, ctx->scene, ctx->ps, (uint32_t)n);
+            hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL((k_trace_inst<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         }
-        hipLaunchKernelGGL(k_trace_out, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, ctx->ps, (uint32_t)n, d_out);
+        hipLaunchKernelGGL(k_trace_out, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, pp.ps, (uint32_t)n, d_out);
         e = hipMemcpyAsync(out, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
