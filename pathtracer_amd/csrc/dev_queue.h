@@ -1,0 +1,47 @@
+// Producer side of the chunked work queues (layout: dev_scene.h).
+#pragma once
+#include "dev_scene.h"
+
+namespace ptd {
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// A wave's open chunk of one queue.  Both members are the same on all lanes.
+struct WavePush {
+    uint32_t chunk, fill;
+    __device__ __forceinline__ void init() {
+        chunk = QUEUE_EMPTY;
+        fill = 0u;
+    }
+};
+
+// Pads the rest of the open chunk; call once per wave and queue when the wave is done with it.
+__device__ __forceinline__ void wave_push_close(const WavePush &w, uint32_t *entries) {
+    if (w.chunk == QUEUE_EMPTY) return;
+    for (uint32_t i = w.fill + lane_id(); i < QUEUE_CHUNK; i += 64u) entries[(size_t)w.chunk * QUEUE_CHUNK + i] = QUEUE_EMPTY;
+}
+
+// Appends `id` for every lane with want == true.  All 64 lanes of the wave must call it
+// together.  `n_chunks` is the queue's chunk count; the caller guarantees capacity (the
+// host sizes every queue for the worst case: paths / (QUEUE_CHUNK - 63) + producing waves).
+__device__ __forceinline__ void wave_push(WavePush &w, bool want, uint32_t id, uint32_t *entries, uint32_t *n_chunks) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    const uint32_t k = (uint32_t)__popcll(mask);
+    if (w.chunk == QUEUE_EMPTY || w.fill + k > QUEUE_CHUNK) {
+        wave_push_close(w, entries);
+        uint32_t got = 0u;
+        if (lane_id() == 0u) got = atomicAdd(n_chunks, 1u);
+        w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        w.fill = 0u;
+    }
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (want) entries[(size_t)w.chunk * QUEUE_CHUNK + w.fill + rank] = id;
+    w.fill += k;
+}
+
+// Identity of the calling wave in the launch, and the number of waves in it.
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; }
+__device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (blockDim.x / 64u); }
+
+}  // namespace ptd

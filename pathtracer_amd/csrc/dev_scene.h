@@ -61,6 +61,7 @@ struct DevScene {
     DevSet lights;  // sets[1]
     uint32_t n_materials;
     uint32_t n_light_total;  // lights.len() including instances
+    uint32_t boxes_finite;   // every coordinate of every BVH box is a finite number
 };
 
 struct DevCamera {
@@ -78,15 +79,27 @@ struct DevCamera {
 
 constexpr int MAX_QUEUES = PTS_MAT_COUNT;
 
-// Device-side launch bookkeeping.  Counters with two copies are used in ping-pong by
-// bounce parity so that a kernel can clear the copy the next kernel will fill.
-struct DevCounters {
-    uint32_t ray_count[2];                // entries in ray queue [parity]
-    uint32_t shade_count[2][MAX_QUEUES];  // entries per material queue [parity][slot]
-    uint32_t walk_cursor[2][8];           // entries of ray queue [parity] handed out so far, per queue region
-};
+// Work queues of path slots, in chunks of QUEUE_CHUNK entries.  A producing wave owns one
+// open chunk per queue it writes and appends to it without synchronisation; it takes a new
+// chunk (one atomic on the queue's chunk count) when the open one cannot take the next
+// push, and pads what it leaves unused with QUEUE_EMPTY.  A consumer walks
+// chunks * QUEUE_CHUNK entries and skips the padding.  One atomic per ~QUEUE_CHUNK entries
+// instead of one per wave push matters: atomics on one 64-byte line run at about 11 ns
+// each on this part whatever the number of waves, which at one per 64 entries was the
+// longest pole of the first bounces.
+constexpr uint32_t QUEUE_CHUNK = 256;
+constexpr uint32_t QUEUE_EMPTY = 0xFFFFFFFFu;
 
-// Per-path state, indexed by slot = (stratum - batch_first_stratum) * W*H + pixel.
+// Control words live one per 256-byte line (atomics on neighbouring lines do not serialise).
+// Words with two copies are used in ping-pong by bounce parity so that a kernel can clear
+// the copy the next kernel will fill.
+constexpr uint32_t CTL_STRIDE = 64;  // in 32-bit words
+constexpr uint32_t CTL_RAY_CHUNKS = 0;    // +parity: chunks in ray queue [parity]
+constexpr uint32_t CTL_RAY_CURSOR = 2;    // +parity: 64-entry pieces of ray queue [parity] handed out so far
+constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material queue [queue]
+constexpr uint32_t CTL_WORDS = (4 + 2 * MAX_QUEUES) * CTL_STRIDE;
+
+// Per-path state, indexed by slot = pixel * strata_in_batch + (stratum - batch_first_stratum).
 struct PathState {
     float4 *ray_o;    // origin.xyz, rng draw counter (bits)
     float4 *ray_d;    // direction.xyz, remaining depth (bits)
@@ -94,13 +107,16 @@ struct PathState {
     float4 *hit;      // t, u, v, global primitive index (bits)
     uint32_t *hit2;   // type | (instance+1) << 2, or PTD_HIT_MISS
     float4 *contrib;  // radiance of the finished path (xyz)
-    uint32_t *ray_queue[2];
-    uint32_t *shade_queue[MAX_QUEUES];  // capacity n_slots each, only used slots allocated
-    DevCounters *ctr;
+    uint32_t *ray_queue[2];             // max_chunks * QUEUE_CHUNK entries each
+    uint32_t *shade_queue[MAX_QUEUES];  // likewise; only the queues of material types in use exist
+    uint32_t *ctl;                      // CTL_WORDS control words
+    uint32_t max_chunks;
+    uint32_t n_queues;
     uint2 *overflow;           // traversal stack levels beyond LDS: [level][overflow_stride]
     uint32_t overflow_stride;  // lanes of the widest traversal launch
     uint32_t n_slots;
     int refill_below;          // a traversing wave with fewer busy lanes than this goes back for more rays
+    int leaf_batch;            // lanes that must be waiting at a leaf before the wave runs a primitive test
 };
 
 }  // namespace ptd

@@ -17,14 +17,12 @@
 // pops never conflict); entries beyond LDS_LEVELS spill to a private array that real
 // scenes do not reach.
 #pragma once
-#include "dev_scene.h"
+#include "dev_queue.h"
 
 namespace ptd {
 
 constexpr int BLOCK = 256;      // threads per workgroup of the traversal kernels
 constexpr int LDS_LEVELS = 16;  // stack entries per lane held in LDS (8 B each: 32 KB per workgroup)
-
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 struct TravRay {
     f3 o, d, inv_d;
@@ -143,6 +141,27 @@ __device__ __forceinline__ bool slab_test_entry(float lx, float ly, float lz, fl
     slab_axis(lx, hx, r.o.x, r.inv_d.x, t_min, t_max);
     slab_axis(ly, hy, r.o.y, r.inv_d.y, t_min, t_max);
     slab_axis(lz, hz, r.o.z, r.inv_d.z, t_min, t_max);
+    entry = t_min;
+    return !(t_max < t_min);
+}
+
+// slab_test_entry for rays on which no product in it can be a NaN: the origin is finite and
+// each 1/d is finite and not zero (a NaN needs 0 * inf or inf - inf), the box being finite
+// too.  Without NaNs each select of the exact form is a min or a max: (t0 < t1 ? t0 : t1)
+// is min(t0, t1), `if (tn > t_min) t_min = tn` is max(t_min, tn), and so on; a zero of the
+// other sign may come out, which no comparison downstream can tell apart.
+__device__ __forceinline__ bool ray_is_plain(const TravRay &r) {
+    const float big = 3.0e38f;  // finite and nonzero: 0 < |x| <= big is false for 0, inf and NaN
+    return fabsf(r.inv_d.x) <= big && fabsf(r.inv_d.y) <= big && fabsf(r.inv_d.z) <= big && r.inv_d.x != 0.0f && r.inv_d.y != 0.0f &&
+           r.inv_d.z != 0.0f && fabsf(r.o.x) <= big && fabsf(r.o.y) <= big && fabsf(r.o.z) <= big;
+}
+__device__ __forceinline__ bool slab_test_entry_plain(float lx, float ly, float lz, float hx, float hy, float hz, const TravRay &r,
+                                                      float &entry) {
+    const float ax = (lx - r.o.x) * r.inv_d.x, bx = (hx - r.o.x) * r.inv_d.x;
+    const float ay = (ly - r.o.y) * r.inv_d.y, by = (hy - r.o.y) * r.inv_d.y;
+    const float az = (lz - r.o.z) * r.inv_d.z, bz = (hz - r.o.z) * r.inv_d.z;
+    const float t_min = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), r.t_min);
+    const float t_max = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), r.t_max);
     entry = t_min;
     return !(t_max < t_min);
 }

@@ -52,38 +52,32 @@ __device__ __forceinline__ void slot_to_sample(const BatchParams &bp, uint32_t s
     stratum = bp.stratum_first + (slot - pixel * bp.n_strata);
 }
 
-// Work split of a device-counted queue of n entries over the launch: the eight groups of
-// workgroups with equal blockIdx.x % 8 (observed to share an XCD, hence an L2) each take one
-// contiguous eighth of the queue and walk it in workgroup-sized steps.  Only speed depends on
-// the placement assumption; every entry is visited exactly once whatever the placement.
-struct QueueWalk {
-    uint32_t begin, end, step;
+// Consumer side of a chunked queue with a fixed share per wave: wave w takes the 64-entry
+// pieces w, w + waves, ... of the chunks in use.
+struct PieceWalk {
+    uint32_t piece, n_pieces, step;
 };
-__device__ __forceinline__ QueueWalk queue_walk(uint32_t n) {
-    const uint32_t groups = 8u;
-    const uint32_t g = blockIdx.x % groups, bi = blockIdx.x / groups;
-    const uint32_t per_group = (gridDim.x - g + groups - 1u) / groups;  // workgroups in this group
-    const uint32_t seg = ((n + groups * BLOCK - 1u) / (groups * BLOCK)) * BLOCK;
-    QueueWalk w;
-    const uint64_t b = (uint64_t)g * seg, e = b + seg;
-    w.begin = (uint32_t)(b < n ? b : n) + bi * BLOCK;
-    w.end = (uint32_t)(e < n ? e : n);
-    w.step = per_group * BLOCK;
-    return w;
+__device__ __forceinline__ PieceWalk piece_walk(uint32_t n_chunks) {
+    return PieceWalk{wave_index(), n_chunks * (QUEUE_CHUNK / 64u), wave_count()};
 }
 
-// Appends `id` to a queue for every lane with want == true: one atomic per wave reserves
-// the range, each lane's position inside it is its rank among the wanting lanes.
-__device__ __forceinline__ void wave_push(bool want, uint32_t id, uint32_t *queue, uint32_t *count) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    const uint32_t total = (uint32_t)__popcll(mask);
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane_id() == leader) base = atomicAdd(count, total);
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (want) queue[base + rank] = id;
+// Open chunks of the material queues, one set per wave of the workgroup, kept in LDS
+// because their number is only known at run time.  Only the owning wave touches its row.
+__shared__ uint32_t g_shade_push[BLOCK / 64][MAX_QUEUES][2];
+__device__ __forceinline__ void shade_push_init() {
+    const uint32_t l = lane_id();
+    if (l < MAX_QUEUES) {
+        g_shade_push[threadIdx.x / 64u][l][0] = QUEUE_EMPTY;
+        g_shade_push[threadIdx.x / 64u][l][1] = 0u;
+    }
+}
+__device__ __forceinline__ void shade_push_close(const PathState &ps) {
+    for (uint32_t q = 0; q < ps.n_queues; q++) {
+        WavePush w;
+        w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_shade_push[threadIdx.x / 64u][q][0]);
+        w.fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_shade_push[threadIdx.x / 64u][q][1]);
+        wave_push_close(w, ps.shade_queue[q]);
+    }
 }
 
 // Camera::get_ray (src/camera.rs:238-260) for one (pixel, stratum).
@@ -126,9 +120,14 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, B
         ps.contrib[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         ps.ray_queue[0][slot] = slot;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ps.ctr->ray_count[0] = n;
-        atomicAdd(&stats->paths_total, (unsigned long long)n);
+    const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
+        if (threadIdx.x == 0) {
+            ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
+            atomicAdd(&stats->paths_total, (unsigned long long)n);
+            atomicAdd(&stats->rays_total, (unsigned long long)n);
+        }
     }
 }
 
@@ -152,7 +151,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // After the closest hit is known: missed paths and paths that hit a primitive without
 // material finish here (src/camera.rs:371, :277-283); the others are appended to the queue
 // of their material type.  Every lane of the wave must call this (inactive lanes with
-// active == false).
+// active == false), after shade_push_init() and before shade_push_close().
 __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, uint32_t parity, f3 background, bool active,
                                          uint32_t slot, uint32_t code, uint32_t prim) {
     uint32_t qslot = 0xFFu;
@@ -174,10 +173,28 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
     unsigned long long todo = __ballot(qslot != 0xFFu);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t q = (uint32_t)__shfl((int)qslot, leader, 64);
+        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qslot, leader);
         const bool mine = qslot == q;
-        wave_push(mine, slot, ps.shade_queue[q], &ps.ctr->shade_count[parity][q]);
+        uint32_t *state = g_shade_push[threadIdx.x / 64u][q];
+        WavePush w;
+        w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[0]);
+        w.fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[1]);
+        wave_push(w, mine, slot, ps.shade_queue[q], &ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE]);
+        if (lane_id() == 0u) {
+            state[0] = w.chunk;
+            state[1] = w.fill;
+        }
         todo &= ~__ballot(mine);
+    }
+}
+
+// What every closest-hit kernel does first: clear the control words the shade kernels of
+// this bounce will fill, and count the launch.
+__device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t parity, uint32_t n_chunks, DevStats *stats) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
+        ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
+        if (n_chunks) atomicAdd(&stats->extend_nonempty, 1ull);
     }
 }
 
@@ -197,28 +214,21 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
 template <bool WIDE, bool COUNT, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
-    const uint32_t n = ps.ctr->ray_count[parity];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ps.ctr->ray_count[parity ^ 1u] = 0u;
-        if (n) {
-            atomicAdd(&stats->rays_total, (unsigned long long)n);
-            atomicAdd(&stats->extend_nonempty, 1ull);
-        }
-    }
+    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    extend_prologue(ps, parity, n_chunks, stats);
+    if (CLASSIFY) shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
-    const QueueWalk qw = queue_walk(n);
-    for (uint32_t i0 = qw.begin; i0 < qw.end; i0 += qw.step) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool active = i < qw.end;
-        uint32_t slot = 0;
+    const PieceWalk pw = piece_walk(n_chunks);
+    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
+        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
+        const bool active = slot != QUEUE_EMPTY;
         HitState h;
         h.code = PTD_HIT_MISS;
         h.prim = 0;
         if (active) {
-            slot = queue[i];
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
             hit_world_prims<WIDE>(sc, r, h, st, tc);
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
         }
         if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim);
     }
+    if (CLASSIFY) shade_push_close(ps);
     flush_counters(COUNT, tc, stats);
 }
 
@@ -234,27 +245,21 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
 // the form used for rendering whenever the scene's leaves fit the 64-byte node layout.
 template <bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK) void k_extend_walk(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
-    const uint32_t n = ps.ctr->ray_count[parity];
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < WALK_REGIONS) ps.ctr->walk_cursor[parity ^ 1u][threadIdx.x] = 0u;
-        if (threadIdx.x == 0) {
-            ps.ctr->ray_count[parity ^ 1u] = 0u;
-            if (n) {
-                atomicAdd(&stats->rays_total, (unsigned long long)n);
-                atomicAdd(&stats->extend_nonempty, 1ull);
-            }
-        }
-    }
-    if (n == 0u) return;
+    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    extend_prologue(ps, parity, n_chunks, stats);
+    if (n_chunks == 0u) return;
+    if (CLASSIFY) shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     const uint32_t *queue = ps.ray_queue[parity];
     walk_world_prims(
-        sc, n, ps.ctr->walk_cursor[parity], ps.refill_below, st,
+        sc, n_chunks, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = queue[i];
+            if (slot == QUEUE_EMPTY) return false;
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            return true;
         },
         [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
             if (done) {
@@ -263,27 +268,27 @@ __global__ __launch_bounds__(BLOCK) void k_extend_walk(DevScene sc, PathState ps
             }
             if (CLASSIFY) classify(sc, ps, parity, background, done, slot, h.code, h.prim);
         });
+    if (CLASSIFY) shade_push_close(ps);
 }
 
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
 // continuing from the hit and t_max the first kernel left; then classification.
 template <bool WIDE, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
-    const uint32_t n = ps.ctr->ray_count[parity];
+    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
-    const QueueWalk qw = queue_walk(n);
-    for (uint32_t i0 = qw.begin; i0 < qw.end; i0 += qw.step) {
-        const uint32_t i = i0 + threadIdx.x;
-        const bool active = i < qw.end;
-        uint32_t slot = 0;
+    const PieceWalk pw = piece_walk(n_chunks);
+    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
+        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
+        const bool active = slot != QUEUE_EMPTY;
         HitState h;
         h.code = PTD_HIT_MISS;
         h.prim = 0;
         if (active) {
-            slot = queue[i];
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot], h4 = ps.hit[slot];
             h.u = h4.y;
             h.v = h4.z;
@@ -300,23 +305,25 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
         }
         classify(sc, ps, parity, background, active, slot, h.code, h.prim);
     }
+    shade_push_close(ps);
     flush_counters(COUNT, tc, stats);
 }
 
 // One path vertex for every path whose hit has a material of type MT: the body of
 // Camera::ray_color after the hit (src/camera.rs:286-369), in multiplicative form.
 template <int MT>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t parity, uint32_t q) {
-    const uint32_t n = ps.ctr->shade_count[parity][q];
-    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->shade_count[parity ^ 1u][q] = 0u;
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t parity, uint32_t q, DevStats *stats) {
+    const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
     const uint32_t *queue = ps.shade_queue[q];
-    const QueueWalk qw = queue_walk(n);
-    for (uint32_t i0 = qw.begin; i0 < qw.end; i0 += qw.step) {
-        const uint32_t i = i0 + threadIdx.x;
+    WavePush out;
+    out.init();
+    uint32_t survivors = 0u;
+    const PieceWalk pw = piece_walk(n_chunks);
+    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
         bool alive = false;
-        uint32_t slot = 0;
-        if (i < qw.end) {
-            slot = queue[i];
+        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
+        if (slot != QUEUE_EMPTY) {
             const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
             const uint32_t code = ps.hit2[slot];
             const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -386,7 +393,14 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
                 }
             }
         }
-        if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) wave_push(alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctr->ray_count[parity ^ 1u]);
+        if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
+            survivors += (uint32_t)__popcll(__ballot(alive));
+            wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
+        }
+    }
+    if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
+        wave_push_close(out, ps.ray_queue[parity ^ 1u]);
+        if (survivors && lane_id() == 0u) atomicAdd(&stats->rays_total, (unsigned long long)survivors);  // rays of the next bounce
     }
 }
 
@@ -429,8 +443,14 @@ __global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathStat
         ps.ray_d[i] = make_float4(r[3], r[4], r[5], r[7]);
         ps.ray_queue[0][i] = i;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctr->ray_count[0] = n;
-    if (blockIdx.x == 0 && threadIdx.x < WALK_REGIONS) ps.ctr->walk_cursor[0][threadIdx.x] = 0u;
+    const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
+    if (blockIdx.x == 0) {
+        for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
+        if (threadIdx.x == 0) {
+            ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
+            ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE] = 0u;
+        }
+    }
 }
 
 // Closest hit for caller-supplied rays with their own [t_min, t_max]: the same two parts.
@@ -452,11 +472,13 @@ __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps,
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     walk_world_prims(
-        sc, n, ps.ctr->walk_cursor[0], ps.refill_below, st,
+        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK, &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            slot = i;
-            const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
+            slot = ps.ray_queue[0][i];
+            if (slot == QUEUE_EMPTY) return false;
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+            return true;
         },
         [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
             if (done) {
@@ -525,7 +547,7 @@ struct pt_context {
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
-    int refill_below = 40, blocks_per_cu = 5;
+    int refill_below = 24, leaf_batch = 8, blocks_per_cu = 4, shade_blocks_per_cu = 8;
     bool trace_bounces = false, static_walk = false;
 
     // scene
@@ -615,11 +637,11 @@ static int grid_for(const pt_context *ctx, uint64_t n) {
     return (int)std::max<uint64_t>(1, std::min(blocks, cap));
 }
 // Kernels whose element count lives in device memory are launched at a fixed size.
-static int grid_fixed(const pt_context *ctx, uint64_t upper_bound) {
+static int grid_fixed(const pt_context *ctx, uint64_t upper_bound, int blocks_per_cu = 0) {
     uint64_t blocks = (upper_bound + BLOCK - 1) / BLOCK;
-    uint64_t cap = (uint64_t)ctx->n_cu * ctx->blocks_per_cu;  // 5 workgroups of 32 KB LDS fit one CU
+    uint64_t cap = (uint64_t)ctx->n_cu * (blocks_per_cu ? blocks_per_cu : ctx->blocks_per_cu);  // 5 workgroups of 32 KB LDS fit one CU
     blocks = std::max<uint64_t>(1, std::min(blocks, cap));
-    return (int)((blocks + 7) / 8 * 8);  // queue_walk splits the work over eight groups of workgroups
+    return (int)((blocks + 7) / 8 * 8);  // the same number of workgroups on every XCD
 }
 
 static void destroy_pipes(pt_context *ctx) {
@@ -660,7 +682,9 @@ int pt_create(int device, pt_context **out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = getenv("PT_TUNE_REFILL")) ctx->refill_below = atoi(v);
+    if (const char *v = getenv("PT_TUNE_LEAF_BATCH")) ctx->leaf_batch = atoi(v);
     if (const char *v = getenv("PT_TUNE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, atoi(v));
+    if (const char *v = getenv("PT_TUNE_SHADE_BLOCKS_PER_CU")) ctx->shade_blocks_per_cu = std::max(1, atoi(v));
     ctx->trace_bounces = getenv("PT_TUNE_TRACE") != nullptr;
     ctx->static_walk = getenv("PT_TUNE_STATIC") != nullptr;
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
@@ -754,7 +778,7 @@ static bool nodes_ok(const pt_node *nodes, uint32_t count, uint32_t prim_count, 
 // The first nodes of the result are the top of the tree in breadth-first order (they are
 // what every ray touches); below that each subtree is laid out depth-first so that a
 // descent walks forward through memory.  Returns false when a leaf does not fit the packed
-// reference (more than 127 primitives, or an offset of 2^24 or more).
+// reference (no primitive, more than 127 primitives, or an offset of 2^24 or more).
 struct WideBuild {
     uint32_t wide_first, root_ref, depth;
     float rmin[3], rmax[3];
@@ -766,7 +790,7 @@ static bool build_wide(const pt_node *nodes, uint32_t count, std::vector<float4>
     out.depth = 1;
     auto leaf_ref = [](const pt_node &n, uint32_t &ref) {
         const uint32_t size = n.b & 0x7FFFFFFFu;
-        if (size > 127u || n.a >= (1u << 24)) return false;
+        if (size == 0u || size > 127u || n.a >= (1u << 24)) return false;
         ref = WIDE_LEAF | (size << 24) | n.a;
         return true;
     };
@@ -960,6 +984,9 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     for (uint32_t k = 2; k < s->n_sets; k++) child_depth = std::max(child_depth, set_depth[k]);
     ctx->stack_need = std::max(set_depth[0], world_inst_depth + child_depth) + 2u;
     ctx->wide_ok = wide_ok;
+    bool boxes_finite = true;
+    for (uint32_t i = 0; i < s->n_nodes && boxes_finite; i++)
+        for (int k = 0; k < 3; k++) boxes_finite = boxes_finite && std::isfinite(s->nodes[i].bmin[k]) && std::isfinite(s->nodes[i].bmax[k]);
     std::vector<DevMaterial> mats(s->n_materials);
     static_assert(sizeof(DevMaterial) == sizeof(pt_material_desc), "material layout");
     if (s->n_materials) std::memcpy(mats.data(), s->materials, (size_t)s->n_materials * sizeof(DevMaterial));
@@ -1013,6 +1040,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     d.lights = sets[1];
     d.n_materials = s->n_materials;
     d.n_light_total = sets[1].tris.prim_count + sets[1].spheres.prim_count + sets[1].quads.prim_count + sets[1].insts.prim_count;
+    d.boxes_finite = boxes_finite ? 1u : 0u;
     ctx->scene = d;
     ctx->have_scene = true;
     // shade queues depend on which material types exist: drop path state so it is rebuilt
@@ -1078,16 +1106,23 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit, n_slots))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit2, n_slots))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.contrib, n_slots))) return rc;
+    // queue capacity: a closed chunk holds more than QUEUE_CHUNK - 64 entries, and every wave of
+    // the largest launch may leave one open chunk behind
+    const uint64_t max_waves = (uint64_t)ctx->n_cu * std::max({ctx->blocks_per_cu, ctx->shade_blocks_per_cu, 8}) * (BLOCK / 64);
+    const uint64_t max_chunks = n_slots / (QUEUE_CHUNK - 63u) + max_waves + 8u;
+    ps.max_chunks = (uint32_t)max_chunks;
+    ps.n_queues = ctx->n_queues;
     for (int k = 0; k < 2; k++)
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_queue[k], n_slots))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_queue[k], max_chunks * QUEUE_CHUNK))) return rc;
     for (uint32_t q = 0; q < ctx->n_queues; q++)
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctr, 1))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
     ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
     const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
     ps.refill_below = ctx->refill_below;
+    ps.leaf_batch = ctx->leaf_batch;
     pp.ps = ps;
     pp.capacity = n_slots;
     return PT_OK;
@@ -1137,7 +1172,7 @@ struct ShadeLaunch {
 };
 template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
-    hipLaunchKernelGGL(k_shade<MT>, dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.parity, l.q);
+    hipLaunchKernelGGL(k_shade<MT>, dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.parity, l.q, l.ctx->stats);
 }
 static void launch_shade_type(int type, const ShadeLaunch &l) {
     switch (type) {
@@ -1191,22 +1226,23 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     if (rc) return rc;
     BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->bsdf_prob};
     hipStream_t st = pp.stream;
-    HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctr, 0, sizeof(DevCounters), st));
+    HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
     pp.ps.n_slots = (uint32_t)n_slots;
     pp.ps.refill_below = ctx->refill_below;
+    pp.ps.leaf_batch = ctx->leaf_batch;
     const PathState ps = pp.ps;
     size_t ev = 0;
     const bool prof = ctx->profile;
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, n_slots)), dim3(BLOCK), 0, st, ctx->cam, ps, bp, ctx->stats);
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-    const int grid = grid_fixed(ctx, n_slots);
+    const int grid = grid_fixed(ctx, n_slots), grid_shade = grid_fixed(ctx, n_slots, ctx->shade_blocks_per_cu);
     const uint32_t depth = ctx->cam.max_depth;
     for (uint32_t b = 0; b < depth; b++) {
         const uint32_t parity = b & 1u;
         launch_extend(ctx, st, grid, ps, parity);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid, &bp, parity, q});
+        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &bp, parity, q});
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
     HIP_TRY(ctx, hipGetLastError());
