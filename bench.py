@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--strata-per-step", type=int, default=64)
     ap.add_argument("--scene", default="knob", choices=["knob", "cornell", "dragon_box", "interior", "next_week_like"])
+    ap.add_argument("--pipes", type=int, default=0, help="batches in flight per GPU (0: library default)")
+    ap.add_argument("--refill-below", type=int, default=0)
+    ap.add_argument("--leaf-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -71,7 +74,8 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import PT_OPT_COUNTERS, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, HostScene, Renderer
+    from pathtracer_amd.core import (PT_OPT_COUNTERS, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+                                     HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
     if not torch.cuda.is_available():
@@ -88,6 +92,12 @@ def main():
     r = Renderer(host, device=local_rank)
     S = args.strata_per_step
     npix = r.npix
+    if args.pipes:
+        r.set_option(PT_OPT_PIPES, args.pipes)
+    if args.refill_below:
+        r.set_option(PT_OPT_REFILL_BELOW, args.refill_below)
+    if args.leaf_batch:
+        r.set_option(PT_OPT_LEAF_BATCH, args.leaf_batch)
     total_strata = r.sqrt_spp * r.sqrt_spp
     need = (args.warmup + args.steps) * S
     lo, hi = stratum_ranges(total_strata, world)[rank]
@@ -123,8 +133,7 @@ def main():
     r.set_option(PT_OPT_PROFILE, 0)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(st["rays"]), float(st["paths"]), st["extend_ms"], float(st["extend_launches"]), st["shade_ms"]],
-                       dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(st["rays"]), float(st["paths"])], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -144,9 +153,20 @@ def main():
         r.set_option(PT_OPT_COUNTERS, 0)
         rays_c = max(1, sc["rays"])
         b_ray = (B_NODE * sc["node_tests"] + B_TRI * sc["tri_tests"] + B_SPHERE * sc["sphere_tests"] + B_QUAD * sc["quad_tests"]) / rays_c + B_RAY_IO
-        ext_ms_per_launch = st["extend_ms"] / max(1, st["extend_launches"])
-        rays_per_launch = st["rays"] / max(1, st["extend_launches"])
-        achieved = (rays_per_launch * b_ray) / (ext_ms_per_launch * 1e-3) / 1e9 if ext_ms_per_launch > 0 else 0.0
+        # The closest-hit kernel on this rank over the timed region.  Launches of different batches
+        # overlap (several batches are in flight, each on its own stream), so the rate is taken over
+        # the time during which at least one launch was running; the per-launch figures are averages
+        # over the launches that had rays, each bracketed by HIP events on its own stream.
+        launches = max(1, st["extend_launches"])
+        ext_ms_per_launch = st["extend_ms"] / launches
+        rays_per_launch = st["rays"] / launches
+        busy_s = st["extend_busy_ms"] * 1e-3
+        achieved = st["rays"] * b_ray / busy_s / 1e9 if busy_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if args.scene == "knob" and os.path.exists(tpath):  # HBM bytes per ray from rocprofv3 --pmc passes over this command
+            with open(tpath) as f:
+                traffic = json.load(f)["hbm_bytes_per_ray"] * rays_per_launch
         out = {
             "metric": "Mrays/s & spp/s, mitsuba knob 768^2 Disney" if args.scene == "knob" else f"Mrays/s & spp/s, {args.scene}",
             "value": rays_all / dt / 1e6,
@@ -162,8 +182,10 @@ def main():
                                    f"(procedural stand-in for mitsuba_smooth.obj), Disney + Lambertian + emitter, {S} strata per step per GPU",
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce"},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
+                         "launches": st["extend_launches"], "busy_ms": st["extend_busy_ms"],
+                         "launches_in_flight": st["extend_ms"] / st["extend_busy_ms"] if st["extend_busy_ms"] > 0 else 0.0,
                          "node_tests_per_ray": sc["node_tests"] / rays_c, "tri_tests_per_ray": sc["tri_tests"] / rays_c},
             "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "other": st["other_ms"]},
             "image_mean": float(img.mean()),

@@ -143,7 +143,9 @@ typedef struct pt_stats {
     uint64_t rays;            /* rays traced by pt_render since the last reset (all bounces) */
     uint64_t paths;           /* camera paths started */
     uint64_t extend_launches; /* launches of the closest-hit kernel that had work */
-    double extend_ms;         /* their summed device time (only with PT_OPT_PROFILE) */
+    double extend_ms;         /* their summed device time (only with PT_OPT_PROFILE); launches of different
+                                 batches overlap, so this can exceed the wall time */
+    double extend_busy_ms;    /* time during which at least one of them was running (union of their intervals) */
     double shade_ms;
     double other_ms;
     double render_ms;         /* host wall time inside pt_render */
@@ -157,7 +159,10 @@ enum {
     PT_OPT_MAX_PATHS = 1,               /* upper bound on paths in flight per batch; default 2^24 */
     PT_OPT_PROFILE = 2,                 /* 1: bracket kernels with HIP events, fill *_ms */
     PT_OPT_COUNTERS = 3,                /* 1: count AABB / primitive tests (implies the reference-order traversal) */
-    PT_OPT_TRAVERSAL = 4                /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes */
+    PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes */
+    PT_OPT_PIPES = 5,                   /* batches of one render call in flight at once, each on its own stream; 1..8, default 4 */
+    PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 24 */
+    PT_OPT_LEAF_BATCH = 7               /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 8 */
 };
 
 typedef struct pt_context pt_context;

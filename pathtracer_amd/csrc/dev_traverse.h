@@ -22,7 +22,7 @@
 namespace ptd {
 
 constexpr int BLOCK = 256;      // threads per workgroup of the traversal kernels
-constexpr int LDS_LEVELS = 16;  // stack entries per lane held in LDS (8 B each: 32 KB per workgroup)
+constexpr int LDS_LEVELS = 15;  // stack entries per lane held in LDS (8 B each: 30 KB per workgroup, five workgroups per CU)
 
 struct TravRay {
     f3 o, d, inv_d;

@@ -548,7 +548,6 @@ struct pt_context {
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
     int refill_below = 24, leaf_batch = 8, blocks_per_cu = 4, shade_blocks_per_cu = 8;
-    bool trace_bounces = false, static_walk = false;
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -582,6 +581,9 @@ struct pt_context {
     DevStats *stats = nullptr;
 
     // profiling
+    hipEvent_t epoch = nullptr;                      // time zero of the current render call
+    std::vector<std::pair<float, float>> extend_iv;  // (start, end) of its closest-hit launches, ms since epoch
+    double extend_busy_ms = 0;                       // time during which at least one closest-hit launch was running
     double extend_ms = 0, shade_ms = 0, other_ms = 0, render_ms = 0;
     uint64_t device_bytes = 0;
 };
@@ -657,6 +659,8 @@ static void destroy_pipes(pt_context *ctx) {
         pp.stream = nullptr;
     }
     ctx->stream = nullptr;
+    if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
+    ctx->epoch = nullptr;
 }
 static void sync_pipes(pt_context *ctx) {
     for (auto &pp : ctx->pipes)
@@ -681,18 +685,12 @@ int pt_create(int device, pt_context **out) {
     }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *v = getenv("PT_TUNE_REFILL")) ctx->refill_below = atoi(v);
-    if (const char *v = getenv("PT_TUNE_LEAF_BATCH")) ctx->leaf_batch = atoi(v);
-    if (const char *v = getenv("PT_TUNE_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(1, atoi(v));
-    if (const char *v = getenv("PT_TUNE_SHADE_BLOCKS_PER_CU")) ctx->shade_blocks_per_cu = std::max(1, atoi(v));
-    ctx->trace_bounces = getenv("PT_TUNE_TRACE") != nullptr;
-    ctx->static_walk = getenv("PT_TUNE_STATIC") != nullptr;
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
-    if (const char *v = getenv("PT_TUNE_PIPES")) ctx->n_pipes = std::min((int)pt_context::MAX_PIPES, std::max(1, atoi(v)));
     ctx->pipes[0].stream = ctx->stream;
+    e = hipEventCreate(&ctx->epoch);
     for (int i = 0; i < pt_context::MAX_PIPES && e == hipSuccess; i++) {
         if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated, hipEventDisableTiming);
@@ -737,6 +735,19 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_PROFILE: ctx->profile = value != 0.0; return PT_OK;
         case PT_OPT_COUNTERS: ctx->counters = value != 0.0; return PT_OK;
         case PT_OPT_TRAVERSAL: ctx->force_ref_order = value != 0.0; return PT_OK;
+        case PT_OPT_PIPES:
+            if (!(value >= 1.0 && value <= (double)pt_context::MAX_PIPES)) return fail(ctx, PT_ERR_INVALID, "pipes must be in [1,%d]", pt_context::MAX_PIPES);
+            sync_pipes(ctx);
+            ctx->n_pipes = (int)value;
+            return PT_OK;
+        case PT_OPT_REFILL_BELOW:
+            if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "refill threshold must be in [1,64]");
+            ctx->refill_below = (int)value;
+            return PT_OK;
+        case PT_OPT_LEAF_BATCH:
+            if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "leaf batch must be in [1,64]");
+            ctx->leaf_batch = (int)value;
+            return PT_OK;
     }
     return fail(ctx, PT_ERR_INVALID, "unknown option %d", key);
 }
@@ -1146,8 +1157,6 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
 #define EXI(W, C) hipLaunchKernelGGL((k_extend_inst<W, C>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
     if (ctx->counters) {
         if (insts) { EXT(false, true, false); EXI(false, true); } else EXT(false, true, true);
-    } else if (ctx->use_wide() && ctx->static_walk) {
-        if (insts) { EXT(true, false, false); EXI(true, false); } else EXT(true, false, true);
     } else if (ctx->use_wide()) {
         if (insts) {
             hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
@@ -1208,7 +1217,8 @@ static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp) {
     for (uint32_t b = 0; b < depth; b++) {
         (void)hipEventElapsedTime(&ms, pp.events[1 + 2 * b], pp.events[2 + 2 * b]);
         ctx->extend_ms += ms;
-        if (ctx->trace_bounces && b < 12) fprintf(stderr, "bounce %u extend %.3f ms\n", b, ms);
+        float since = 0;
+        if (hipEventElapsedTime(&since, ctx->epoch, pp.events[1 + 2 * b]) == hipSuccess) ctx->extend_iv.push_back({since, since + ms});
         (void)hipEventElapsedTime(&ms, pp.events[2 + 2 * b], pp.events[3 + 2 * b]);
         ctx->shade_ms += ms;
     }
@@ -1274,6 +1284,12 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     // pixel receives its samples in stratum order whatever the overlap (camera.rs:212-217).
     hipEvent_t prev_accumulated = nullptr;
     uint32_t batch = 0;
+    if (ctx->profile) {
+        for (int i = 0; i < ctx->n_pipes; i++) harvest_profile(ctx, ctx->pipes[i]);  // nothing may refer to the old epoch
+        ctx->extend_iv.clear();
+        HIP_TRY(ctx, hipEventRecord(ctx->epoch, ctx->pipes[0].stream));
+        for (int i = 1; i < ctx->n_pipes; i++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipes[i].stream, ctx->epoch, 0));
+    }
     for (uint32_t s = stratum_begin; s < stratum_end; batch++) {
         pt_context::Pipe &pp = ctx->pipes[batch % (uint32_t)ctx->n_pipes];
         const uint32_t k = std::min(per_batch, stratum_end - s);
@@ -1294,6 +1310,21 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     for (int i = 0; i < ctx->n_pipes; i++) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->pipes[i].stream));
         harvest_profile(ctx, ctx->pipes[i]);
+    }
+    if (!ctx->extend_iv.empty()) {  // union of the closest-hit launches of this call
+        std::sort(ctx->extend_iv.begin(), ctx->extend_iv.end());
+        float lo = ctx->extend_iv[0].first, hi = ctx->extend_iv[0].second;
+        for (const auto &iv : ctx->extend_iv) {
+            if (iv.first > hi) {
+                ctx->extend_busy_ms += hi - lo;
+                lo = iv.first;
+                hi = iv.second;
+            } else {
+                hi = std::max(hi, iv.second);
+            }
+        }
+        ctx->extend_busy_ms += hi - lo;
+        ctx->extend_iv.clear();
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1457,6 +1488,7 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
     out->paths = ds.paths_total;
     out->extend_launches = ds.extend_nonempty;
     out->extend_ms = ctx->extend_ms;
+    out->extend_busy_ms = ctx->extend_busy_ms;
     out->shade_ms = ctx->shade_ms;
     out->other_ms = ctx->other_ms;
     out->render_ms = ctx->render_ms;
@@ -1473,7 +1505,7 @@ int pt_stats_reset(pt_context *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
-    ctx->extend_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = 0.0;
+    ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = 0.0;
     return PT_OK;
 }
 

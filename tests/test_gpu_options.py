@@ -1,0 +1,96 @@
+"""Scheduling options of the device library must not change any result: batches in flight, ray refill
+threshold, leaf batching, queue sizes at the chunk boundaries."""
+import numpy as np
+import pytest
+
+from pathtracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def small_mixed_scene():
+    return scenes.small_mixed(32, 16)
+
+
+def cornell_small():
+    return scenes.cornell(48, 16)
+
+
+def _rays(n, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    r = np.zeros((n, 8), np.float32)
+    r[:, :3] = rng.uniform(lo, hi, size=(n, 3))
+    r[:, 3:6] = rng.normal(size=(n, 3))
+    r[:, 6], r[:, 7] = 0.001, np.inf
+    return r
+
+
+def _renderer(src):
+    from pathtracer_amd.core import HostScene, Renderer
+    return Renderer(HostScene(src), device=0)
+
+
+def test_accumulator_identical_for_any_number_of_batches_in_flight():
+    from pathtracer_amd.core import PT_OPT_MAX_PATHS, PT_OPT_PIPES
+    src = small_mixed_scene()
+    ref = None
+    for pipes, max_paths in ((1, 1 << 24), (2, 1 << 24), (4, 1 << 24), (8, 1 << 24), (4, 3 * 32 * 32)):
+        r = _renderer(src)
+        r.set_option(PT_OPT_PIPES, pipes)
+        r.set_option(PT_OPT_MAX_PATHS, max_paths)
+        r.render(0, 13, seed=9)
+        acc, n = r.read_accum()
+        assert n == 13
+        if ref is None:
+            ref = acc
+        else:
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} max_paths={max_paths}"
+
+
+def test_first_hits_identical_for_any_refill_and_leaf_batch():
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import PT_OPT_LEAF_BATCH, PT_OPT_REFILL_BELOW
+    src = small_mixed_scene()
+    oracle = OracleScene(src)
+    rays = _rays(20000, 4, -7, 9)
+    ids, tuv = oracle.trace(rays)
+    for refill, leaf in ((1, 1), (64, 1), (24, 8), (40, 64), (64, 64)):
+        r = _renderer(src)
+        r.set_option(PT_OPT_REFILL_BELOW, refill)
+        r.set_option(PT_OPT_LEAF_BATCH, leaf)
+        hits = r.trace(rays)
+        assert np.array_equal(hits["prim_type"], ids[:, 0]) and np.array_equal(hits["prim_id"], ids[:, 1]), (refill, leaf)
+        assert np.array_equal(hits["inst_id"], ids[:, 2]), (refill, leaf)
+        assert np.array_equal(hits["t"].view(np.uint32), tuv[:, 0].view(np.uint32)), (refill, leaf)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023, 4097])
+def test_trace_sizes_around_the_queue_chunk(n):
+    from oracle.pyoracle import OracleScene
+    src = cornell_small()
+    oracle = OracleScene(src)
+    rays = _rays(n, n, 0, 555)
+    ids, tuv = oracle.trace(rays)
+    hits = _renderer(src).trace(rays)
+    assert hits.shape[0] == n
+    assert np.array_equal(hits["prim_type"], ids[:, 0]) and np.array_equal(hits["prim_id"], ids[:, 1]) and np.array_equal(hits["inst_id"], ids[:, 2])
+    assert np.array_equal(hits["t"].view(np.uint32), tuv[:, 0].view(np.uint32))
+
+
+def test_option_ranges_are_checked():
+    from pathtracer_amd.core import PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_REFILL_BELOW, PtError
+    r = _renderer(cornell_small())
+    for key, bad in ((PT_OPT_PIPES, 0), (PT_OPT_PIPES, 9), (PT_OPT_REFILL_BELOW, 0), (PT_OPT_REFILL_BELOW, 65), (PT_OPT_LEAF_BATCH, 0)):
+        with pytest.raises(PtError):
+            r.set_option(key, bad)
+
+
+def test_per_sample_radiance_identical_across_options():
+    from pathtracer_amd.core import PT_OPT_LEAF_BATCH, PT_OPT_REFILL_BELOW
+    src = small_mixed_scene()
+    a = _renderer(src).render_samples(0, 3, seed=2)
+    r = _renderer(src)
+    r.set_option(PT_OPT_REFILL_BELOW, 1)
+    r.set_option(PT_OPT_LEAF_BATCH, 1)
+    b = r.render_samples(0, 3, seed=2)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
