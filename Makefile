@@ -37,3 +37,7 @@ clean:
 resources:
 	$(HIPCC) $(filter-out -shared -fPIC,$(HIPFLAGS)) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage -o /dev/null $(CORE_SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* //' | paste - - - - - -
 .PHONY: resources
+
+# Microbenchmarks behind design decisions (run on the GPU box).
+tools/micro/atomic_rate: tools/micro/atomic_rate.hip
+	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<

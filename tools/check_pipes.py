@@ -5,14 +5,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 def run(pipes, out):
-    env = dict(os.environ, PT_TUNE_PIPES=str(pipes))
+    env = dict(os.environ)
     code = f"""
 import sys; sys.path.insert(0, {ROOT!r})
 import numpy as np
 from pathtracer_amd import scenes
-from pathtracer_amd.core import HostScene, Renderer
+from pathtracer_amd.core import HostScene, Renderer, PT_OPT_PIPES
 src = scenes.knob(width=256)
 r = Renderer(HostScene(src), device=0)
+r.set_option(PT_OPT_PIPES, {pipes})
 r.render(0, 64, seed=3)
 acc, n = r.read_accum()
 img = r.read_rgb8()
