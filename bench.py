@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--pipes", type=int, default=0, help="batches in flight per GPU (0: library default)")
     ap.add_argument("--refill-below", type=int, default=0)
     ap.add_argument("--leaf-batch", type=int, default=0)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -74,7 +75,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_COUNTERS, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_COUNTERS, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -98,6 +99,8 @@ def main():
         r.set_option(PT_OPT_REFILL_BELOW, args.refill_below)
     if args.leaf_batch:
         r.set_option(PT_OPT_LEAF_BATCH, args.leaf_batch)
+    if args.blocks_per_cu:
+        r.set_option(PT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     total_strata = r.sqrt_spp * r.sqrt_spp
     need = (args.warmup + args.steps) * S
     lo, hi = stratum_ranges(total_strata, world)[rank]
@@ -110,6 +113,7 @@ def main():
 
     for k in range(args.warmup):
         step(k)
+    r.sync()
     r.reset_accum()
     r.stats_reset()
     r.set_option(PT_OPT_PROFILE, 1)
@@ -178,8 +182,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{src.name} scene {r.width}x{r.height}, depth {src.camera.max_depth}, {host.desc.n_tris} triangles "
-                                   f"(procedural stand-in for mitsuba_smooth.obj), Disney + Lambertian + emitter, {S} strata per step per GPU",
+            "config": {"workload": f"{src.name} scene {r.width}x{r.height}, depth {src.camera.max_depth}, {host.desc.n_tris} triangles, "
+                                   f"{host.desc.n_spheres} spheres, {host.desc.n_quads} quads, {host.desc.n_instances} instances"
+                                   + (" (procedural stand-in for mitsuba_smooth.obj, Disney + Lambertian + emitter)" if args.scene == "knob" else "")
+                                   + f", {S} full-frame strata per step per GPU",
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce"},
             "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -162,7 +162,8 @@ enum {
     PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes */
     PT_OPT_PIPES = 5,                   /* batches of one render call in flight at once, each on its own stream; 1..8, default 4 */
     PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 24 */
-    PT_OPT_LEAF_BATCH = 7               /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 8 */
+    PT_OPT_LEAF_BATCH = 7,              /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 8 */
+    PT_OPT_BLOCKS_PER_CU = 8            /* resident workgroups per CU of the traversal kernels; 1..5, default 4 */
 };
 
 typedef struct pt_context pt_context;
@@ -180,9 +181,17 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *scene);
 int pt_set_camera(pt_context *ctx, const pt_camera_desc *camera);
 
 /* Camera::render for the strata [stratum_begin, stratum_end) of the s_u-major sample
- * list (src/camera.rs:176-181); blocking; adds into the accumulator and the pass count
- * (src/camera.rs:199, :212-217).  The generator is keyed by (seed, pixel, stratum). */
+ * list (src/camera.rs:176-181): adds into the accumulator and the pass count
+ * (src/camera.rs:199, :212-217).  The generator is keyed by (seed, pixel, stratum).
+ * The work is enqueued on the device and the call returns (it waits only so as not to run
+ * more than two batches ahead of each pipe); successive calls overlap on the device, and
+ * every pixel still receives its samples in stratum order of the calls.  Every entry point
+ * that reads results (pt_read_*, pt_copy_accum_to_device, pt_stats_get, ...) waits for all
+ * rendering enqueued before it; pt_sync waits without reading anything. */
 int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed);
+/* No counterpart in the reference (its render() blocks): waits for the rendering enqueued
+ * so far and reports an asynchronous device error, if any. */
+int pt_sync(pt_context *ctx);
 
 /* As pt_render, but instead of accumulating returns every sample's radiance before the
  * NaN filter: out[(stratum - stratum_begin) * W*H + pixel][3] (host memory). */

@@ -21,7 +21,7 @@ _host: Optional[C.CDLL] = None
 
 PT_NODE_LEAF = 0x80000000
 (PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS, PT_OPT_TRAVERSAL, PT_OPT_PIPES,
- PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH) = range(8)
+ PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_BLOCKS_PER_CU) = range(9)
 
 
 class PtError(RuntimeError):
@@ -83,7 +83,7 @@ class pt_stats(C.Structure):
 HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
 
 # every symbol include/ptcore.h and include/pthost.h declare
-CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render",
+CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
                 "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum",
                 "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
 HOST_SYMBOLS = ["pth_scene_build", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render"]
@@ -100,6 +100,7 @@ def core_lib() -> C.CDLL:
         L.pt_last_error.argtypes = [vp]
         L.pt_last_error.restype = C.c_char_p
         L.pt_set_option.argtypes = [vp, C.c_int, C.c_double]
+        L.pt_sync.argtypes = [vp]
         L.pt_upload_scene.argtypes = [vp, vp]
         L.pt_set_camera.argtypes = [vp, vp]
         L.pt_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
@@ -238,7 +239,11 @@ class Renderer:
         self._check(self.L.pt_set_option(self.ctx, key, float(value)), "pt_set_option")
 
     def render(self, stratum_begin: int, stratum_end: int, seed: int = 0):
+        """Enqueues the strata; returns without waiting for the device (see ``sync``)."""
         self._check(self.L.pt_render(self.ctx, stratum_begin, stratum_end, seed), "pt_render")
+
+    def sync(self):
+        self._check(self.L.pt_sync(self.ctx), "pt_sync")
 
     def render_samples(self, stratum_begin: int, stratum_end: int, seed: int = 0) -> np.ndarray:
         out = np.zeros((stratum_end - stratum_begin, self.npix, 3), np.float32)

@@ -22,7 +22,10 @@
 namespace ptd {
 
 constexpr int BLOCK = 256;      // threads per workgroup of the traversal kernels
-constexpr int LDS_LEVELS = 15;  // stack entries per lane held in LDS (8 B each: 30 KB per workgroup, five workgroups per CU)
+#ifndef PT_LDS_LEVELS
+#define PT_LDS_LEVELS 15
+#endif
+constexpr int LDS_LEVELS = PT_LDS_LEVELS;  // stack entries per lane held in LDS (8 B each: 30 KB per workgroup, five workgroups per CU)
 
 struct TravRay {
     f3 o, d, inv_d;
@@ -58,8 +61,13 @@ struct TravCounters {
 //     sizes it from the depth of the uploaded BVHs, so it cannot be overrun.
 __shared__ uint2 g_lane_stack[LDS_LEVELS * BLOCK];
 
+// The overflow array is addressed through a pointer that says "global memory" in its type:
+// a pop chooses between an LDS and a global load, and with a generic pointer on one side the
+// compiler folds the two into one flat_load, which pays for both paths on every pop.
+typedef __attribute__((address_space(1))) uint2 GlobalUint2;
+
 struct LaneStack {
-    uint2 *overflow;  // [levels][stride]
+    GlobalUint2 *overflow;  // [levels][stride]
     uint32_t stride;  // lanes in the launch
     uint32_t gtid;
     uint32_t top_ref;
@@ -67,7 +75,7 @@ struct LaneStack {
     bool has_top;
     int sp;  // entries below the register slot
     __device__ __forceinline__ void init(uint2 *ovf, uint32_t lanes) {
-        overflow = ovf;
+        overflow = (GlobalUint2 *)ovf;
         stride = lanes;
         gtid = blockIdx.x * BLOCK + threadIdx.x;
         has_top = false;
@@ -78,7 +86,11 @@ struct LaneStack {
     __device__ __forceinline__ void spill_top() {
         const uint2 v = make_uint2(top_ref, __float_as_uint(top_e));
         if (sp < LDS_LEVELS) g_lane_stack[sp * BLOCK + threadIdx.x] = v;
-        else overflow[(size_t)(sp - LDS_LEVELS) * stride + gtid] = v;
+        else {
+            GlobalUint2 *p = overflow + ((size_t)(sp - LDS_LEVELS) * stride + gtid);
+            p->x = v.x;
+            p->y = v.y;
+        }
         sp++;
     }
     __device__ __forceinline__ void push(uint32_t ref, float e) {
@@ -97,7 +109,13 @@ struct LaneStack {
         }
         if (sp == floor) return false;
         sp--;
-        const uint2 v = sp < LDS_LEVELS ? g_lane_stack[sp * BLOCK + threadIdx.x] : overflow[(size_t)(sp - LDS_LEVELS) * stride + gtid];
+        uint2 v;
+        if (sp < LDS_LEVELS) {
+            v = g_lane_stack[sp * BLOCK + threadIdx.x];
+        } else {
+            const GlobalUint2 *p = overflow + ((size_t)(sp - LDS_LEVELS) * stride + gtid);
+            v = make_uint2(p->x, p->y);
+        }
         ref = v.x;
         e = __uint_as_float(v.y);
         return true;

@@ -243,8 +243,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
 
 // The same step with rays drawn by the waves as their lanes fall idle (dev_walk.h); this is
 // the form used for rendering whenever the scene's leaves fit the 64-byte node layout.
+#ifdef PT_WALK_WAVES
+#define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
+#else
+#define WALK_OCCUPANCY
+#endif
 template <bool CLASSIFY>
-__global__ __launch_bounds__(BLOCK) void k_extend_walk(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
     extend_prologue(ps, parity, n_chunks, stats);
     if (n_chunks == 0u) return;
@@ -547,7 +552,12 @@ struct pt_context {
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
-    int refill_below = 24, leaf_batch = 8, blocks_per_cu = 4, shade_blocks_per_cu = 8;
+#ifdef PT_WALK_WAVES
+    int blocks_per_cu = PT_WALK_WAVES;
+#else
+    int blocks_per_cu = 4;
+#endif
+    int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -571,13 +581,18 @@ struct pt_context {
         PathState ps{};
         std::vector<std::pair<void *, size_t>> allocs;
         uint64_t capacity = 0;
-        hipEvent_t accumulated = nullptr;  // recorded after the batch's k_accumulate
-        std::vector<hipEvent_t> events;    // profiling: raygen, per-bounce extend/shade, accumulate
-        uint32_t events_pending = 0;       // bounces whose events have not been read back yet
+        hipEvent_t accumulated[2] = {nullptr, nullptr};  // recorded after a batch's k_accumulate, alternately
+        uint64_t batches = 0;                            // batches enqueued on this pipe so far
+        // profiling: raygen, per-bounce extend/shade, accumulate; two sets used alternately so that
+        // reading one back never waits for the batch just enqueued
+        std::vector<hipEvent_t> events[2];
+        uint32_t events_pending[2] = {0, 0};  // bounces whose events have not been read back yet
     };
     static constexpr int MAX_PIPES = 8;
     Pipe pipes[MAX_PIPES];
     int n_pipes = 4;
+    uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
+    hipEvent_t last_accumulated = nullptr;  // of the most recent batch: the next k_accumulate waits for it
     DevStats *stats = nullptr;
 
     // profiling
@@ -651,10 +666,14 @@ static void destroy_pipes(pt_context *ctx) {
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
         free_pool(ctx, pp.allocs);
         pp.capacity = 0;
-        for (hipEvent_t ev : pp.events) (void)hipEventDestroy(ev);
-        pp.events.clear();
-        if (pp.accumulated) (void)hipEventDestroy(pp.accumulated);
-        pp.accumulated = nullptr;
+        for (auto &set : pp.events) {
+            for (hipEvent_t ev : set) (void)hipEventDestroy(ev);
+            set.clear();
+        }
+        for (auto &ev : pp.accumulated) {
+            if (ev) (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
         if (pp.stream) (void)hipStreamDestroy(pp.stream);
         pp.stream = nullptr;
     }
@@ -668,6 +687,47 @@ static void sync_pipes(pt_context *ctx) {
 }
 
 // The entry points below have C linkage through their declarations in ptcore.h.
+static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp);
+
+// Waits for everything enqueued on the context and folds in pending event timings.
+static int sync_all(pt_context *ctx) {
+    for (auto &pp : ctx->pipes) {
+        if (!pp.stream) continue;
+        HIP_TRY(ctx, hipStreamSynchronize(pp.stream));
+        harvest_profile(ctx, pp);
+    }
+    if (!ctx->extend_iv.empty()) {  // union of the closest-hit launches since the last call
+        std::sort(ctx->extend_iv.begin(), ctx->extend_iv.end());
+        float lo = ctx->extend_iv[0].first, hi = ctx->extend_iv[0].second;
+        for (const auto &iv : ctx->extend_iv) {
+            if (iv.first > hi) {
+                ctx->extend_busy_ms += hi - lo;
+                lo = iv.first;
+                hi = iv.second;
+            } else {
+                hi = std::max(hi, iv.second);
+            }
+        }
+        ctx->extend_busy_ms += hi - lo;
+        ctx->extend_iv.clear();
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
+}
+// Time zero for the event intervals of the profile.
+static int restart_epoch(pt_context *ctx) {
+    int rc = sync_all(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->epoch, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->epoch));
+    return PT_OK;
+}
+
+int pt_sync(pt_context *ctx) {
+    if (!ctx) return PT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return sync_all(ctx);
+}
 
 int pt_create(int device, pt_context **out) {
     if (!out) return fail(nullptr, PT_ERR_INVALID, "pt_create: out is NULL");
@@ -693,7 +753,7 @@ int pt_create(int device, pt_context **out) {
     e = hipEventCreate(&ctx->epoch);
     for (int i = 0; i < pt_context::MAX_PIPES && e == hipSuccess; i++) {
         if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated, hipEventDisableTiming);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated[k], hipEventDisableTiming);
     }
     void *p = nullptr;
     if (e != hipSuccess || (e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
@@ -732,7 +792,12 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             if (!(value >= 1.0 && value <= 4.0e9)) return fail(ctx, PT_ERR_INVALID, "max paths out of range");
             ctx->max_paths = (uint64_t)value;
             return PT_OK;
-        case PT_OPT_PROFILE: ctx->profile = value != 0.0; return PT_OK;
+        case PT_OPT_PROFILE: {
+            int rc = restart_epoch(ctx);
+            if (rc) return rc;
+            ctx->profile = value != 0.0;
+            return PT_OK;
+        }
         case PT_OPT_COUNTERS: ctx->counters = value != 0.0; return PT_OK;
         case PT_OPT_TRAVERSAL: ctx->force_ref_order = value != 0.0; return PT_OK;
         case PT_OPT_PIPES:
@@ -743,6 +808,15 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_REFILL_BELOW:
             if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "refill threshold must be in [1,64]");
             ctx->refill_below = (int)value;
+            return PT_OK;
+        case PT_OPT_BLOCKS_PER_CU:
+            if (!(value >= 1.0 && value <= 5.0)) return fail(ctx, PT_ERR_INVALID, "workgroups per CU must be in [1,5] (LDS holds five traversal stacks)");
+            sync_pipes(ctx);
+            ctx->blocks_per_cu = (int)value;
+            for (auto &pp : ctx->pipes) {  // the stack overflow area is sized by the launch width
+                free_pool(ctx, pp.allocs);
+                pp.capacity = 0;
+            }
             return PT_OK;
         case PT_OPT_LEAF_BATCH:
             if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "leaf batch must be in [1,64]");
@@ -1083,7 +1157,7 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
     d.inv_sqrt_spp = c->inv_sqrt_spp;
     d.max_depth = c->max_depth;
     d.background = v(c->background);
-    (void)hipStreamSynchronize(ctx->stream);
+    sync_pipes(ctx);
     const uint64_t npix = (uint64_t)d.width * d.height;
     if (!ctx->have_camera || (uint64_t)ctx->cam.width * ctx->cam.height != npix) {
         if (ctx->accum) (void)hipFree(ctx->accum);
@@ -1140,12 +1214,13 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
 }
 
 static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
-    while (pp.events.size() <= i) {
+    auto &set = pp.events[pp.batches & 1u];
+    while (set.size() <= i) {
         hipEvent_t ev;
         if (hipEventCreate(&ev) != hipSuccess) return nullptr;
-        pp.events.push_back(ev);
+        set.push_back(ev);
     }
-    return pp.events[i];
+    return set[i];
 }
 
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
@@ -1205,25 +1280,30 @@ static uint64_t mix64_host(uint64_t z) {
 }
 
 // Reads back the event timings a pipe still holds (profiling only); waits for that batch.
-static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp) {
-    if (!pp.events_pending) return;
-    const uint32_t depth = pp.events_pending;
-    pp.events_pending = 0;
+static void harvest_set(pt_context *ctx, pt_context::Pipe &pp, int which) {
+    if (!pp.events_pending[which]) return;
+    const uint32_t depth = pp.events_pending[which];
+    pp.events_pending[which] = 0;
+    const auto &evs = pp.events[which];
     const size_t last = 3 + 2 * (size_t)depth;
-    if (pp.events.size() <= last || hipEventSynchronize(pp.events[last]) != hipSuccess) return;
+    if (evs.size() <= last || hipEventSynchronize(evs[last]) != hipSuccess) return;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, pp.events[0], pp.events[1]);
+    (void)hipEventElapsedTime(&ms, evs[0], evs[1]);
     ctx->other_ms += ms;
     for (uint32_t b = 0; b < depth; b++) {
-        (void)hipEventElapsedTime(&ms, pp.events[1 + 2 * b], pp.events[2 + 2 * b]);
+        (void)hipEventElapsedTime(&ms, evs[1 + 2 * b], evs[2 + 2 * b]);
         ctx->extend_ms += ms;
         float since = 0;
-        if (hipEventElapsedTime(&since, ctx->epoch, pp.events[1 + 2 * b]) == hipSuccess) ctx->extend_iv.push_back({since, since + ms});
-        (void)hipEventElapsedTime(&ms, pp.events[2 + 2 * b], pp.events[3 + 2 * b]);
+        if (hipEventElapsedTime(&since, ctx->epoch, evs[1 + 2 * b]) == hipSuccess) ctx->extend_iv.push_back({since, since + ms});
+        (void)hipEventElapsedTime(&ms, evs[2 + 2 * b], evs[3 + 2 * b]);
         ctx->shade_ms += ms;
     }
-    (void)hipEventElapsedTime(&ms, pp.events[last - 1], pp.events[last]);
+    (void)hipEventElapsedTime(&ms, evs[last - 1], evs[last]);
     ctx->other_ms += ms;
+}
+static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp) {
+    harvest_set(ctx, pp, 0);
+    harvest_set(ctx, pp, 1);
 }
 
 // Enqueues one batch (strata [first, first + k)) on a pipe: every bounce, no host wait.
@@ -1231,7 +1311,7 @@ static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp) {
 static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint32_t k, uint64_t seed) {
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
     const uint64_t n_slots = (uint64_t)npix * k;
-    harvest_profile(ctx, pp);
+    harvest_set(ctx, pp, (int)(pp.batches & 1u));  // the set this batch is about to record into
     int rc = ensure_paths(ctx, pp, n_slots);
     if (rc) return rc;
     BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->bsdf_prob};
@@ -1273,58 +1353,36 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     auto t0 = std::chrono::steady_clock::now();
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
-    // Batch size: at most max_paths paths, and small enough that the request keeps every
-    // pipe busy, but not below about a million paths (a launch has to fill the chip).
+    // Batches as large as max_paths allows and of equal size: the bigger the batch, the smaller
+    // the share of its thin late bounces; consecutive calls keep the other pipes busy.
     const uint32_t total = stratum_end - stratum_begin;
+    if (total == 0) return PT_OK;
     const uint32_t cap = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
-    const uint32_t floor_k = (uint32_t)std::max<uint64_t>(1, ((1ull << 20) + npix - 1) / npix);
-    const uint32_t even = (total + (uint32_t)ctx->n_pipes - 1) / (uint32_t)ctx->n_pipes;
-    const uint32_t per_batch = std::min(cap, std::max(even, floor_k));
+    const uint32_t n_batches = (total + cap - 1) / cap;
+    const uint32_t per_batch = (total + n_batches - 1) / n_batches;
     // k_accumulate of batch i runs on batch i's stream after batch i-1's k_accumulate, so each
     // pixel receives its samples in stratum order whatever the overlap (camera.rs:212-217).
-    hipEvent_t prev_accumulated = nullptr;
-    uint32_t batch = 0;
-    if (ctx->profile) {
-        for (int i = 0; i < ctx->n_pipes; i++) harvest_profile(ctx, ctx->pipes[i]);  // nothing may refer to the old epoch
-        ctx->extend_iv.clear();
-        HIP_TRY(ctx, hipEventRecord(ctx->epoch, ctx->pipes[0].stream));
-        for (int i = 1; i < ctx->n_pipes; i++) HIP_TRY(ctx, hipStreamWaitEvent(ctx->pipes[i].stream, ctx->epoch, 0));
-    }
-    for (uint32_t s = stratum_begin; s < stratum_end; batch++) {
-        pt_context::Pipe &pp = ctx->pipes[batch % (uint32_t)ctx->n_pipes];
+    for (uint32_t s = stratum_begin; s < stratum_end;) {
+        pt_context::Pipe &pp = ctx->pipes[ctx->batch_seq % (uint64_t)ctx->n_pipes];
         const uint32_t k = std::min(per_batch, stratum_end - s);
+        // the host runs at most two batches ahead of each pipe
+        hipEvent_t done = pp.accumulated[pp.batches & 1u];
+        if (pp.batches >= 2) HIP_TRY(ctx, hipEventSynchronize(done));
         if ((rc = run_batch(ctx, pp, s, k, seed))) return rc;
-        if (prev_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(pp.stream, prev_accumulated, 0));
+        if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(pp.stream, ctx->last_accumulated, 0));
         const size_t ev = 2 + 2 * (size_t)ctx->cam.max_depth;
         if (ctx->profile) (void)hipEventRecord(get_event(pp, ev), pp.stream);
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, pp.stream, pp.ps.contrib, ctx->accum, npix, k);
         if (ctx->profile) {
             (void)hipEventRecord(get_event(pp, ev + 1), pp.stream);
-            pp.events_pending = ctx->cam.max_depth;
+            pp.events_pending[pp.batches & 1u] = ctx->cam.max_depth;
         }
-        HIP_TRY(ctx, hipEventRecord(pp.accumulated, pp.stream));
-        prev_accumulated = pp.accumulated;
+        HIP_TRY(ctx, hipEventRecord(done, pp.stream));
+        ctx->last_accumulated = done;
+        pp.batches++;
+        ctx->batch_seq++;
         ctx->n_samples += k;  // `samples += 1` per pass (camera.rs:199)
         s += k;
-    }
-    for (int i = 0; i < ctx->n_pipes; i++) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->pipes[i].stream));
-        harvest_profile(ctx, ctx->pipes[i]);
-    }
-    if (!ctx->extend_iv.empty()) {  // union of the closest-hit launches of this call
-        std::sort(ctx->extend_iv.begin(), ctx->extend_iv.end());
-        float lo = ctx->extend_iv[0].first, hi = ctx->extend_iv[0].second;
-        for (const auto &iv : ctx->extend_iv) {
-            if (iv.first > hi) {
-                ctx->extend_busy_ms += hi - lo;
-                lo = iv.first;
-                hi = iv.second;
-            } else {
-                hi = std::max(hi, iv.second);
-            }
-        }
-        ctx->extend_busy_ms += hi - lo;
-        ctx->extend_iv.clear();
     }
     HIP_TRY(ctx, hipGetLastError());
     ctx->render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1430,7 +1488,7 @@ int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples) {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     const size_t npix = (size_t)ctx->cam.width * ctx->cam.height;
     if (rgb_sum) HIP_TRY(ctx, hipMemcpy(rgb_sum, ctx->accum, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (n_samples) *n_samples = ctx->n_samples;
@@ -1442,6 +1500,7 @@ int pt_read_rgb8(pt_context *ctx, uint8_t *rgb) {
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    if (int rc = sync_all(ctx)) return rc;
     hipLaunchKernelGGL(k_tonemap, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->accum, ctx->rgb8, npix, (float)ctx->n_samples);
     HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->rgb8, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1452,7 +1511,7 @@ int pt_reset_accum(pt_context *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     HIP_TRY(ctx, hipMemset(ctx->accum, 0, (size_t)ctx->cam.width * ctx->cam.height * 3 * sizeof(float)));
     ctx->n_samples = 0;
     return PT_OK;
@@ -1462,6 +1521,7 @@ int pt_copy_accum_to_device(pt_context *ctx, void *dst_device) {
     if (!ctx || !dst_device) return fail(ctx, PT_ERR_INVALID, "NULL argument");
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_all(ctx)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(dst_device, ctx->accum, (size_t)ctx->cam.width * ctx->cam.height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
@@ -1471,6 +1531,7 @@ int pt_set_accum_from_device(pt_context *ctx, const void *src_device, uint32_t n
     if (!ctx || !src_device) return fail(ctx, PT_ERR_INVALID, "NULL argument");
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (int rc = sync_all(ctx)) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->accum, src_device, (size_t)ctx->cam.width * ctx->cam.height * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->n_samples = n_samples;
@@ -1480,7 +1541,7 @@ int pt_set_accum_from_device(pt_context *ctx, const void *src_device, uint32_t n
 int pt_stats_get(pt_context *ctx, pt_stats *out) {
     if (!ctx || !out) return fail(ctx, PT_ERR_INVALID, "NULL argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     DevStats ds;
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->stats, sizeof ds, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof *out);
@@ -1503,7 +1564,7 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
 int pt_stats_reset(pt_context *ctx) {
     if (!ctx) return PT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = restart_epoch(ctx)) return rc;
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
     ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = 0.0;
     return PT_OK;
