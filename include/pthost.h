@@ -38,6 +38,33 @@ uint32_t pth_perm(const pth_scene *s, int set, int type, uint32_t *out);
  * stratum of the camera, writes W*H*3 bytes to rgb8.  Returns a PT_ERR_* code. */
 int pth_camera_render(const pth_scene *s, pt_context *ctx, uint64_t seed, uint8_t *rgb8);
 
+/* ---- Wavefront .obj files (TriMesh::load_as_vec, src/objects/tri_mesh.rs:299-381).
+ * One mesh per model of the file, in file order, with tobj's default options (separate
+ * position / normal / texcoord index streams, faces not triangulated).  NULL on failure
+ * (the reference logs and continues with no meshes); `err` receives the reason. */
+typedef struct pth_obj pth_obj;
+typedef struct pth_obj_mesh {
+    const float *positions;           /* [n_positions][3], in order of first use by the model's faces */
+    uint32_t n_positions;
+    const uint32_t *indices;          /* [n_indices] into positions */
+    uint32_t n_indices;
+    const float *normals;             /* [n_normals][3] or NULL: the model has no normals */
+    uint32_t n_normals;
+    const uint32_t *normal_indices;   /* [n_indices] into normals */
+    const float *texcoords;           /* [n_texcoords][2] or NULL */
+    uint32_t n_texcoords;
+    const uint32_t *texcoord_indices; /* [n_indices] into texcoords */
+} pth_obj_mesh;
+pth_obj *pth_obj_load(const char *path, char *err, size_t errlen);
+void pth_obj_free(pth_obj *o);
+uint32_t pth_obj_mesh_count(const pth_obj *o);
+int pth_obj_mesh_get(const pth_obj *o, uint32_t mesh, pth_obj_mesh *out); /* views valid until pth_obj_free */
+/* TriMesh::to_triangles (tri_mesh.rs:383-415): index streams read three at a time.  Returns
+ * the triangle count (-1: bad mesh index or an index stream that is not a multiple of three)
+ * and fills pos [n][3][3], nrm [n][3][3], uv [n][3][2] where the pointer is not NULL and the
+ * mesh has that attribute; has_normals / has_uvs report which it has. */
+int64_t pth_obj_triangles(const pth_obj *o, uint32_t mesh, float *pos, float *nrm, float *uv, int *has_normals, int *has_uvs);
+
 #ifdef __cplusplus
 }
 #endif

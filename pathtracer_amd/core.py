@@ -86,7 +86,8 @@ HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id"
 CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
                 "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum",
                 "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
-HOST_SYMBOLS = ["pth_scene_build", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render"]
+HOST_SYMBOLS = ["pth_scene_build", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
+                "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles"]
 
 
 def core_lib() -> C.CDLL:
@@ -135,8 +136,44 @@ def host_lib() -> C.CDLL:
         L.pth_perm.argtypes = [vp, C.c_int, C.c_int, vp]
         L.pth_perm.restype = C.c_uint32
         L.pth_camera_render.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pth_obj_load.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.pth_obj_load.restype = vp
+        L.pth_obj_free.argtypes = [vp]
+        L.pth_obj_free.restype = None
+        L.pth_obj_mesh_count.argtypes = [vp]
+        L.pth_obj_mesh_count.restype = C.c_uint32
+        L.pth_obj_mesh_get.argtypes = [vp, C.c_uint32, vp]
+        L.pth_obj_triangles.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.pth_obj_triangles.restype = C.c_int64
         _host = L
     return _host
+
+
+def load_obj(path: str):
+    """TriMesh::load_as_vec + to_triangles (src/objects/tri_mesh.rs:299-415) through the host library:
+    one ``(pos (n,3,3), nrm (n,3,3) or None, uv (n,3,2) or None)`` per model of the file, in file order.
+    Raises PtError where the reference would log the failure and continue with no meshes."""
+    L = host_lib()
+    err = C.create_string_buffer(256)
+    h = L.pth_obj_load(os.fsencode(path), err, len(err))
+    if not h:
+        raise PtError(f"cannot load {path}: {err.value.decode()}")
+    try:
+        out = []
+        for i in range(L.pth_obj_mesh_count(h)):
+            hn, hu = C.c_int(0), C.c_int(0)
+            n = L.pth_obj_triangles(h, i, None, None, None, C.byref(hn), C.byref(hu))
+            if n < 0:
+                raise PtError(f"{path}: model {i} is not triangulated")
+            pos = np.zeros((n, 3, 3), np.float32)
+            nrm = np.zeros((n, 3, 3), np.float32) if hn.value else None
+            uv = np.zeros((n, 3, 2), np.float32) if hu.value else None
+            L.pth_obj_triangles(h, i, pos.ctypes.data_as(C.c_void_p), None if nrm is None else nrm.ctypes.data_as(C.c_void_p),
+                                None if uv is None else uv.ctypes.data_as(C.c_void_p), None, None)
+            out.append((pos, nrm, uv))
+        return out
+    finally:
+        L.pth_obj_free(h)
 
 
 def _arr(ptr, shape, dtype):

@@ -149,6 +149,23 @@ struct Triangle {  // src/objects/tri_mesh.rs:21-75
     Point3 position(int vertex) const { return Point3(data[0][vertex], data[1][vertex], data[2][vertex]); }
     BBox bbox() const;
 };
+// One model of a Wavefront .obj file, as tobj's default (multi-index, untriangulated) export
+// gives it: src/objects/tri_mesh.rs:280-460.
+struct TriMesh {
+    std::vector<Point3> positions;
+    std::vector<uint32_t> position_indices;
+    bool has_normals = false;  // normals: Some(..) in the reference
+    std::vector<Vector3> normals;
+    std::vector<uint32_t> normal_indices;
+    bool has_uvs = false;
+    std::vector<std::array<float, 2>> uvs;
+    std::vector<uint32_t> uv_indices;
+    // One mesh per model, in file order; empty when the file cannot be loaded (the reference
+    // logs and carries on with no meshes).  `error`, if given, receives the reason.
+    static std::vector<TriMesh> load_as_vec(const std::string &path, std::string *error = nullptr);
+    std::vector<Triangle> to_triangles() const;  // material None
+    std::vector<Triangle> to_triangles_with_mat(MaterialRef material) const;
+};
 struct Sphere {  // src/objects/sphere.rs:9-27
     Point3 center;
     float radius;

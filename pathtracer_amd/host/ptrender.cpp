@@ -1,13 +1,17 @@
-// ptrender: the reference's main() without its window (src/main.rs:62-118) — build the
-// Cornell scene with the host scene API, build the BVHs, call Camera::render on a GPU and
-// save the image (PPM instead of the reference's strat.png).
+// ptrender: the reference's main() without its window (src/main.rs:62-118) — build a scene
+// with the host scene API, build the BVHs, call Camera::render on a GPU and save the image
+// (PPM instead of the reference's strat.png).
 //
-// The scene function is src/scenes/cornell.rs:18-133 written against pt:: — it shows what a
-// user of the reference's scene API finds here.
+//     ptrender [width] [spp] [out.ppm]                     the Cornell scene
+//     ptrender object <file.obj> [width] [spp] [out.ppm]   the Object scene on an .obj file
+//
+// The scene functions are src/scenes/cornell.rs:18-133 and src/scenes/object.rs:20-96 written
+// against pt:: — they show what a user of the reference's scene API finds here.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <string>
 
 #include "pthost.hpp"
 
@@ -51,17 +55,46 @@ struct Cornell {
     }
 };
 
+struct Object {
+    static Camera build_camera(uint32_t width, uint32_t spp) {
+        return Camera(1.0f, width, 15.0f, Point3(2.0f, 10.0f, 16.0f), Point3(0.0f, 1.0f, 0.0f), 10.0f, 0.0f, spp, 50, Color(0.0f, 0.0f, 0.0f));
+    }
+    static void build_scene(const std::string &obj_path, PrimitiveBuffer &objects, LightBuffer &lights) {
+        MaterialRegistry materials;
+        std::string why;
+        const std::vector<TriMesh> meshes = TriMesh::load_as_vec(obj_path, &why);
+        if (meshes.empty()) std::fprintf(stderr, "Failed to load mesh: %s... Using empty mesh instead...\n", why.c_str());
+        TextureRef lite = Solid::make(Color(0.6f, 0.6f, 0.6f)), dark = Solid::make(Color(0.2f, 0.2f, 0.2f));
+        TextureRef blue = Solid::make(Color(0.8f, 0.6f, 0.2f));
+        TextureRef check = Checkered::make(lite, dark, 13.0f);
+        materials.create_material("emit", Diffuse::gray(20.0f));
+        materials.create_material("check", Lambertian::new_texture(check));
+        materials.create_material("mat1", Lambertian::make(Color(0.2f, 0.2f, 0.2f)));
+        materials.create_material("test", Disney::make(blue, 0.5f, 0.1f, 0.0f, 0.01f, 0.2f, 0.1f, 0.8f, 0.3f, 0.1f, 0.2f, 0.5f, 1.1f));
+        Sphere light(Point3(-10.0f, 15.0f, 5.0f), 2.0f, materials.get("emit"));
+        lights.add_sphere(light);
+        objects.add_sphere(light);
+        const char *mats[3] = {"check", "mat1", "test"};
+        if (meshes.size() > 3) throw std::runtime_error("the Object scene has materials for three models");
+        for (size_t i = 0; i < meshes.size(); i++)
+            for (Triangle &tri : meshes[i].to_triangles_with_mat(materials.get(mats[i]))) objects.add_triangle(std::move(tri));
+    }
+};
+
 int main(int argc, char **argv) {
-    const uint32_t width = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 768;
-    const uint32_t spp = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 1024;
-    const char *out = argc > 3 ? argv[3] : "strat.ppm";
+    const bool object = argc > 2 && std::string(argv[1]) == "object";
+    const int a0 = object ? 3 : 1;
+    const uint32_t width = argc > a0 ? (uint32_t)std::atoi(argv[a0]) : 768;
+    const uint32_t spp = argc > a0 + 1 ? (uint32_t)std::atoi(argv[a0 + 1]) : 1024;
+    const char *out = argc > a0 + 2 ? argv[a0 + 2] : "strat.ppm";
     try {
         std::fprintf(stderr, "Building scene...\n");
         auto t0 = std::chrono::steady_clock::now();
-        Camera camera = Cornell::build_camera(width, spp);
+        Camera camera = object ? Object::build_camera(width, spp) : Cornell::build_camera(width, spp);
         PrimitiveBuffer objects;
         LightBuffer lights;
-        Cornell::build_scene(objects, lights);
+        if (object) Object::build_scene(argv[2], objects, lights);
+        else Cornell::build_scene(objects, lights);
         objects.build_bvh();
         auto t1 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "Build time: %.3f ms\nRendering...\n", std::chrono::duration<double, std::milli>(t1 - t0).count());

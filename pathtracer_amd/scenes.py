@@ -9,7 +9,7 @@ only a hash-based noise and float64 trigonometry rounded to float32.
 from __future__ import annotations
 
 import math
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -126,11 +126,15 @@ def _sphere_grid(center, radius_fn, n_theta: int, n_phi: int):
     return P, N, UV, TH, PH
 
 
-def knob_meshes(seed: int = 1, detail: int = 1) -> Tuple[tuple, tuple, tuple]:
+def _scaled(n: int, detail: float) -> int:
+    return max(4, int(round(n * detail)))
+
+
+def knob_meshes(seed: int = 1, detail: float = 1) -> Tuple[tuple, tuple, tuple]:
     """Three meshes standing in for the three models of ``mitsuba_smooth.obj`` (``object.rs:60-67``):
     backdrop (uv-mapped), inner core, outer shell with cut-outs.  ~150 k triangles at detail=1."""
     # 0: backdrop sheet, flat in front, curving up behind the object
-    n = 96 * detail
+    n = _scaled(96, detail)
     xs = np.linspace(-14.0, 14.0, n + 1)
     zs = np.linspace(-14.0, 14.0, n + 1)
     Z, X = np.meshgrid(zs, xs, indexing="ij")
@@ -145,12 +149,12 @@ def knob_meshes(seed: int = 1, detail: int = 1) -> Tuple[tuple, tuple, tuple]:
 
     # 1: inner core
     c = (0.0, 1.05, 0.0)
-    P1, N1, UV1, _, _ = _sphere_grid(c, lambda t, p: 0.78 + 0.0 * t, 192 * detail, 96 * detail)
+    P1, N1, UV1, _, _ = _sphere_grid(c, lambda t, p: 0.78 + 0.0 * t, _scaled(192, detail), _scaled(96, detail))
     m1 = _grid_to_tris(P1, N1, UV1)
 
     # 2: outer shell — outer and inner surface of a bumpy sphere with an equatorial band of windows
     # removed, plus a pedestal
-    nt, npx = 288 * detail, 144 * detail
+    nt, npx = _scaled(288, detail), _scaled(144, detail)
 
     def r_out(t, p):
         return 1.22 + 0.035 * (_value_noise(np.mod(t, 2 * np.pi), np.clip(p, 0, np.pi), 24, seed) - 0.5)
@@ -166,7 +170,7 @@ def knob_meshes(seed: int = 1, detail: int = 1) -> Tuple[tuple, tuple, tuple]:
     mo = _grid_to_tris(Po, No, UVo, keep=keep2)
     mi = _grid_to_tris(Pi, -Ni, UVi, keep=keep2, flip=True)
     # pedestal: a cone frustum ring under the shell
-    k = 192 * detail
+    k = _scaled(192, detail)
     tt = np.linspace(0, 2 * np.pi, k + 1)
     hh = np.linspace(0.0, 1.0, 9)
     Hh, Tt = np.meshgrid(hh, tt, indexing="ij")
@@ -181,8 +185,10 @@ def knob_meshes(seed: int = 1, detail: int = 1) -> Tuple[tuple, tuple, tuple]:
 
 
 # --------------------------------------------------------------------------- C3
-def knob(width: int = 768, spp: int = 10240, max_depth: int = 50, seed: int = 1, detail: int = 1) -> SceneSource:
-    """``Object::build_scene`` / ``build_camera`` (``src/scenes/object.rs:22-96``), mesh procedural."""
+def knob(width: int = 768, spp: int = 10240, max_depth: int = 50, seed: int = 1, detail: float = 1, asset: Optional[str] = None) -> SceneSource:
+    """``Object::build_scene`` / ``build_camera`` (``src/scenes/object.rs:22-96``).  The meshes come from
+    ``asset`` (an .obj file, loaded as ``TriMesh::load_as_vec`` does, materials assigned by model order,
+    ``object.rs:60-67``) or, without one, from the procedural stand-in."""
     s = SceneSource()
     s.name = "knob"
     lite = s.solid((0.6, 0.6, 0.6))
@@ -198,8 +204,16 @@ def knob(width: int = 768, spp: int = 10240, max_depth: int = 50, seed: int = 1,
 
     s.lights.add_sphere((-10.0, 15.0, 5.0), 2.0, emit)
     s.objects.add_sphere((-10.0, 15.0, 5.0), 2.0, emit)
-    for (pos, nrm, uv), mat in zip(knob_meshes(seed, detail), (m_check, m_mat1, m_test)):
-        s.objects.add_triangles(pos, nrm, uv, mat)
+    if asset is not None:
+        from .core import load_obj
+        meshes = load_obj(asset)
+        if len(meshes) > 3:
+            raise ValueError(f"{asset}: {len(meshes)} models, the scene has materials for three (object.rs:60)")
+    else:
+        meshes = knob_meshes(seed, detail)
+    for (pos, nrm, uv), mat in zip(meshes, (m_check, m_mat1, m_test)):
+        if pos.shape[0]:
+            s.objects.add_triangles(pos, nrm, uv, mat)
     s.objects.build_bvh = True
     s.camera = CameraSrc(1.0, width, 15.0, (2.0, 10.0, 16.0), (0.0, 1.0, 0.0), 10.0, 0.0, spp, max_depth,
                          (0.0, 0.0, 0.0))
