@@ -33,10 +33,15 @@ clean:
 
 .PHONY: all oracle clean
 
+# The same library with every scene reference checked before use (PTCORE_LIB=... selects it in the Python binding).
+pathtracer_amd/libptcore_check.so: $(CORE_SRC) $(CORE_DEP)
+	$(HIPCC) $(HIPFLAGS) -DPT_BOUNDS_CHECK -o $@ $(CORE_SRC)
+check-lib: pathtracer_amd/libptcore_check.so
+
 # Register / LDS / scratch use of every kernel (no output file).
 resources:
 	$(HIPCC) $(filter-out -shared -fPIC,$(HIPFLAGS)) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage -o /dev/null $(CORE_SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* //' | paste - - - - - -
-.PHONY: resources
+.PHONY: resources check-lib
 
 # Microbenchmarks behind design decisions (run on the GPU box).
 tools/micro/atomic_rate: tools/micro/atomic_rate.hip

@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--strata-per-step", type=int, default=64)
+    ap.add_argument("--strata-per-step", type=int, default=128)
     ap.add_argument("--scene", default="knob", choices=["knob", "cornell", "dragon_box", "interior", "next_week_like"])
     ap.add_argument("--pipes", type=int, default=0, help="batches in flight per GPU (0: library default)")
     ap.add_argument("--refill-below", type=int, default=0)
@@ -102,13 +102,14 @@ def main():
     if args.blocks_per_cu:
         r.set_option(PT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     total_strata = r.sqrt_spp * r.sqrt_spp
-    need = (args.warmup + args.steps) * S
     lo, hi = stratum_ranges(total_strata, world)[rank]
-    if hi - lo < need:
-        raise SystemExit(f"rank {rank}: {hi - lo} strata in its shard, {need} needed")
+    S = min(S, hi - lo)
+    if S <= 0:
+        raise SystemExit(f"rank {rank}: empty stratum shard")
+    span = (hi - lo) - S + 1  # first strata a step may start at; long runs wrap around inside the shard
 
     def step(k):
-        b = lo + k * S
+        b = lo + (k * S) % span
         r.render(b, b + S, seed=1)
 
     for k in range(args.warmup):

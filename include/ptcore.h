@@ -152,6 +152,7 @@ typedef struct pt_stats {
     /* traversal work, only counted with PT_OPT_COUNTERS: */
     uint64_t node_tests, tri_tests, sphere_tests, quad_tests;
     uint64_t device_bytes;    /* device memory held by the context */
+    uint64_t bad_refs;        /* out-of-range scene references caught by a library built with PT_BOUNDS_CHECK (else 0) */
 } pt_stats;
 
 enum {

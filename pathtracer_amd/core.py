@@ -77,7 +77,8 @@ class pt_hit(C.Structure):
 class pt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
                 ("extend_busy_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double), ("render_ms", C.c_double), ("node_tests", C.c_uint64),
-                ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("quad_tests", C.c_uint64), ("device_bytes", C.c_uint64)]
+                ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("quad_tests", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("bad_refs", C.c_uint64)]
 
 
 HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
@@ -93,7 +94,8 @@ HOST_SYMBOLS = ["pth_scene_build", "pth_scene_free", "pth_scene_desc", "pth_came
 def core_lib() -> C.CDLL:
     global _core
     if _core is None:
-        L = C.CDLL(os.path.join(_HERE, "libptcore.so"), mode=C.RTLD_GLOBAL)
+        # PTCORE_LIB: another build of the same library (the bounds-checking one, for debugging)
+        L = C.CDLL(os.environ.get("PTCORE_LIB") or os.path.join(_HERE, "libptcore.so"), mode=C.RTLD_GLOBAL)
         vp = C.c_void_p
         L.pt_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.pt_destroy.argtypes = [vp]

@@ -62,6 +62,7 @@ struct DevScene {
     uint32_t n_materials;
     uint32_t n_light_total;  // lights.len() including instances
     uint32_t boxes_finite;   // every coordinate of every BVH box is a finite number
+    uint32_t n_wide, n_tris, n_spheres, n_quads, n_insts, n_sets;  // array lengths (bounds-checking build)
 };
 
 struct DevCamera {

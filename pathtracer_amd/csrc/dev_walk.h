@@ -1,6 +1,6 @@
-// Persistent-wave closest-hit search over the world's triangle, sphere and quad buffers
-// (the first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194) on 64-byte
-// two-box nodes.
+// Persistent-wave closest-hit search: PrimitiveBuffer::hit (src/objects.rs:191-197) over the
+// world's triangle, sphere and quad buffers and, when INSTANCES, its instance buffer with
+// Instance::hit (src/objects.rs:384-401) into the instanced sets, on 64-byte two-box nodes.
 //
 // Every ray runs exactly the sequence of box and primitive tests of traverse<true> in
 // dev_traverse.h (hence of InnerPrimitiveBuffer::traverse, src/bvh.rs:725-797); what
@@ -18,15 +18,28 @@
 // until `leaf_batch` of them are (or no lane has a node left), so that the primitive test
 // runs with a fair share of the wave; nothing else about a lane's sequence depends on what
 // the other lanes do.
+//
+// Instances.  A "primitive" of the world's instance buffer is an instance: the lane takes
+// its ray into the instance's frame (direction not renormalised, so t is shared between
+// the frames), leaves a return record on its stack and searches the three buffers of the
+// instanced set like the world's, with the instance tag in the hit code.  A hit inside the
+// instance replaces the ray's hit and shrinks its t_max exactly as the reference's local
+// HitRecord does when it is copied out (objects.rs:395-399), so the hit and t_max are
+// updated in place.  When the set's last buffer is exhausted the lane reloads its
+// world-frame ray and goes on with the next instance of the leaf it came from.
 #pragma once
 #include "dev_traverse.h"
 
 namespace ptd {
 
-constexpr uint32_t REF_NONE = 0xFFFFFFFFu;    // no node pending: pop, or go to the next buffer
+// Stack / `cur` values that are not node references.  None can be a leaf reference: all
+// decode to 127 primitives at an offset of at least 2^24 - 3, past the largest offset a
+// leaf may have.
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;    // nothing pending: the stack is empty
 constexpr uint32_t REF_LINEAR = 0xFFFFFFFEu;  // buffer without a BVH: all primitives in order (src/bvh.rs:726-737)
-// Neither value can be a leaf reference: both decode to 127 primitives at an offset of at
-// least 2^24 - 2, past the largest offset a leaf may have.
+constexpr uint32_t REF_RETURN = 0xFFFFFFFDu;  // bottom of an instance's part of the stack; the record below it
+                                              // holds (leaf of the instance buffer in progress, next instance)
+constexpr uint32_t PHASE_INSTS = 3u, PHASE_CHILD = 4u, PHASE_DONE = 7u, PHASE_IDLE = 8u;
 
 // First node of a buffer for ray r: the buffer's own early-outs and the root's box.
 __device__ __forceinline__ uint32_t walk_begin(const DevBuffer &buf, const TravRay &r) {
@@ -37,23 +50,58 @@ __device__ __forceinline__ uint32_t walk_begin(const DevBuffer &buf, const TravR
     return buf.root_ref;
 }
 
-// Next stacked node whose entry distance is still within reach, REF_NONE when the stack is empty.
+// Next stacked node whose entry distance is still within reach; REF_RETURN when the
+// entries of the instance in progress are used up (that record stays on the stack until the
+// lane leaves the instance), REF_NONE when the stack is empty.
 __device__ __forceinline__ uint32_t walk_pop(LaneStack &st, const TravRay &r) {
     uint32_t ref;
     float e;
     for (;;) {
         if (!st.pop(0, ref, e)) return REF_NONE;
+        if (ref == REF_RETURN) {
+            st.push(ref, e);
+            return ref;
+        }
         if (!(r.t_max < e)) return ref;
     }
 }
 
-// source(i, slot, ray): loads queue entry i, false when it is padding.   sink(done, slot,
-// ray, hit): called by all 64 lanes of the wave together (so it may use ballots), done ==
-// true on lanes whose ray has just been finished.  `n_chunks` chunks of the queue are in
-// use; `cursor` counts the 64-entry pieces handed out.
-template <class Source, class Sink>
-__device__ __forceinline__ void walk_world_prims(const DevScene &sc, uint32_t n_chunks, uint32_t *cursor, int refill_below, int leaf_batch, LaneStack &st,
-                                                 Source &&source, Sink &&sink) {
+// A build with PT_BOUNDS_CHECK verifies every node, primitive, instance and set index before
+// it is used; a bad one is counted and ends that ray instead of reading out of range.
+#ifdef PT_BOUNDS_CHECK
+// ... and a lane that is still not done after WALK_MAX_PASSES passes leaves its state behind
+// (phase, cur, li, lend, instance tag, stack depth) and gives up.
+constexpr uint32_t WALK_MAX_PASSES = 1u << 20;
+#define WALK_CHECK(cond, id)                                                              \
+    if (!(cond)) {                                                                        \
+        if (atomicAdd(bad_refs, 1ull) == 0ull) {                                          \
+            bad_refs[2] = phase | ((unsigned long long)(id) << 32);                       \
+            bad_refs[3] = cur | ((unsigned long long)node_base << 32);                    \
+            bad_refs[4] = ((unsigned long long)li << 32) | lend;                          \
+            bad_refs[5] = inst_code | ((unsigned long long)prim_base << 32);              \
+            bad_refs[6] = (unsigned long long)st.sp | (st.has_top ? 1ull << 32 : 0ull);   \
+            bad_refs[7] = slot | ((unsigned long long)child << 32);                       \
+        }                                                                                 \
+        phase = PHASE_DONE;                                                               \
+        cur = REF_NONE;                                                                   \
+        li = lend = 0u;                                                                   \
+        st.sp = 0;                                                                        \
+        st.has_top = false;                                                               \
+        continue;                                                                         \
+    }
+#else
+#define WALK_CHECK(cond, id)
+#endif
+
+// source(i, slot, ray): loads queue entry i, false when it is padding.
+// reload(slot, o, d): the world-frame origin and direction of that ray again (INSTANCES only).
+// sink(done, slot, ray, hit): called by all 64 lanes of the wave together (so it may use
+// ballots), done == true on lanes whose ray has just been finished; ray.t_max is the hit
+// distance.  `n_chunks` chunks of the queue are in use; `cursor` counts the 64-entry pieces
+// handed out.  `bad_refs` is only touched in the bounds-checking build.
+template <bool INSTANCES, class Source, class Reload, class Sink>
+__device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_chunks, uint32_t *cursor, int refill_below, int leaf_batch,
+                                           LaneStack &st, unsigned long long *bad_refs, Source &&source, Reload &&reload, Sink &&sink) {
     const DevSet &set = sc.world;
     constexpr uint32_t PIECES = QUEUE_CHUNK / 64u;
     const uint32_t n_pieces = n_chunks * PIECES;
@@ -62,30 +110,51 @@ __device__ __forceinline__ void walk_world_prims(const DevScene &sc, uint32_t n_
     if ((uint64_t)wave_index() * claim >= n_pieces) return;
     uint32_t res_next = 0u, res_end = 0u;  // claimed entries not dealt yet (same on all lanes)
     bool used_up = false;
-    // phase: 0..2 = buffer being searched, 3 = finished (sink pending), 4 = lane has no ray
-    // cur: the node to visit next, or the leaf whose primitives [li, lend) are pending, or REF_NONE
-    uint32_t phase = 4u, cur = REF_NONE, slot = 0u, node_base = 0u, prim_base = 0u, li = 0u, lend = 0u;
+    // phase: 0..2 = world buffer being searched, 3 = the world's instance buffer, 4..6 = buffer of
+    // the instanced set, PHASE_DONE = finished (sink pending), PHASE_IDLE = lane has no ray
+    // cur: the node to visit next, or the leaf whose primitives [li, lend) are pending, or REF_*
+    uint32_t phase = PHASE_IDLE, cur = REF_NONE, slot = 0u, node_base = 0u, prim_base = 0u, li = 0u, lend = 0u;
+    uint32_t inst_code = 0u, child = 0u;  // (instance + 1) << 2 and its set while inside an instance
+    bool lane_plain = true;               // the min/max box test is exact for this lane's current ray
     TravRay r = make_trav_ray(mk3(0.0f, 0.0f, 0.0f), mk3(1.0f, 1.0f, 1.0f), 0.0f, 0.0f);
     HitState h;
     h.code = PTD_HIT_MISS;
     h.u = h.v = 0.0f;
     h.prim = 0u;
     TravCounters tc{0, 0, 0, 0};
-    auto open_leaf = [&]() {
-        if ((cur & WIDE_LEAF) && cur != REF_NONE) {
-            if (cur == REF_LINEAR) {
-                li = prim_base;
-                lend = li + (phase == 0u ? set.tris.prim_count : (phase == 1u ? set.spheres.prim_count : set.quads.prim_count));
-            } else {
-                li = prim_base + (cur & 0xFFFFFFu);
-                lend = li + ((cur >> 24) & 0x7Fu);
-            }
+    (void)bad_refs;
+#ifdef PT_BOUNDS_CHECK
+    uint32_t passes = 0u, rounds = 0u;
+#endif
+    // [li, lend) of the leaf in `cur`; `count` = primitives of the buffer in progress (for REF_LINEAR)
+    auto open_leaf = [&](uint32_t count) {
+        if ((cur & WIDE_LEAF) && cur < REF_RETURN) {
+            li = prim_base + (cur & 0xFFFFFFu);
+            lend = li + ((cur >> 24) & 0x7Fu);
+        } else if (cur == REF_LINEAR) {
+            li = prim_base;
+            lend = li + count;
         }
     };
+    // Starts the search of one buffer.  Inside an instance an empty or missed buffer means what a
+    // pop down to the instance's stack bottom means.
+    auto begin_buffer = [&](const DevBuffer &buf) {
+        node_base = buf.wide_first;
+        prim_base = buf.prim_first;
+        cur = walk_begin(buf, r);
+        open_leaf(buf.prim_count);
+        if (INSTANCES && cur == REF_NONE && inst_code != 0u) cur = REF_RETURN;
+    };
     for (;;) {
+#ifdef PT_BOUNDS_CHECK
+        if (++rounds > WALK_MAX_PASSES) {
+            if (lane_id() == 0u && atomicAdd(&bad_refs[1], 1ull) == 0ull) bad_refs[2] = 99ull;
+            break;
+        }
+#endif
         // ---- deal new rays to idle lanes
         for (;;) {
-            const unsigned long long idle = __ballot(phase == 4u);
+            const unsigned long long idle = __ballot(phase == PHASE_IDLE);
             if (idle == 0ull) break;
             if (res_next == res_end) {
                 if (used_up) break;
@@ -101,27 +170,36 @@ __device__ __forceinline__ void walk_world_prims(const DevScene &sc, uint32_t n_
             }
             const uint32_t want = (uint32_t)__popcll(idle), avail = res_end - res_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            if (phase == 4u && rank < avail && source(res_next + rank, slot, r)) {
+            if (phase == PHASE_IDLE && rank < avail && source(res_next + rank, slot, r)) {
                 h.code = PTD_HIT_MISS;
                 h.u = h.v = 0.0f;
                 h.prim = 0u;
                 phase = 0u;
-                node_base = set.tris.wide_first;
-                prim_base = set.tris.prim_first;
-                cur = walk_begin(set.tris, r);
-                open_leaf();
+                inst_code = 0u;
+                lane_plain = ray_is_plain(r);
+#ifdef PT_BOUNDS_CHECK
+                passes = 0u;
+#endif
+                begin_buffer(set.tris);
             }
             res_next += want < avail ? want : avail;
         }
-        if (__ballot(phase < 3u) == 0ull) break;  // nothing in flight, so nothing left to claim either
+        if (__ballot(phase < PHASE_DONE) == 0ull) break;  // nothing in flight, so nothing left to claim either
 
         // ---- traverse until too few lanes are busy
         const bool can_refill = !used_up || res_next != res_end;
         // min/max form of the box test when no ray of the wave can produce a NaN in it
-        const bool plain = sc.boxes_finite != 0u && __ballot(phase < 3u && !ray_is_plain(r)) == 0ull;
-        while (phase < 3u) {
+        bool plain = sc.boxes_finite != 0u && __ballot(phase < PHASE_DONE && !lane_plain) == 0ull;
+        while (phase < PHASE_DONE) {
+#ifdef PT_BOUNDS_CHECK
+            if (++passes > WALK_MAX_PASSES) {
+                atomicAdd(&bad_refs[1], 1ull);
+                WALK_CHECK(false, 5)
+            }
+#endif
             // (A) one interior node, for the lanes that have one pending
             if (!(cur & WIDE_LEAF)) {
+                WALK_CHECK(node_base + cur < sc.n_wide, 1)
                 const float4 *w = sc.wide + 4 * (size_t)(node_base + cur);
                 const float4 a = w[0], b = w[1], c = w[2], d = w[3];
                 float el, er;
@@ -147,45 +225,95 @@ __device__ __forceinline__ void walk_world_prims(const DevScene &sc, uint32_t n_
                 } else {
                     cur = walk_pop(st, r);
                 }
-                open_leaf();
+                open_leaf(0u);  // a reference out of a node or off the stack is never REF_LINEAR
             }
             // (B) one primitive of a pending leaf, once enough lanes have one or no lane has a node left
             {
                 const unsigned long long at_leaf = __ballot(li < lend), at_node = __ballot(!(cur & WIDE_LEAF));
                 if (at_leaf != 0ull && (at_node == 0ull || __popcll(at_leaf) >= leaf_batch)) {
                     if (li < lend) {
-                        if (phase == 0u) hit_prim<PT_PRIM_TRI>(sc, li, r, h, 0u, tc);
-                        else if (phase == 1u) hit_prim<PT_PRIM_SPHERE>(sc, li, r, h, 0u, tc);
-                        else hit_prim<PT_PRIM_QUAD>(sc, li, r, h, 0u, tc);
-                        li++;
-                        if (li == lend) {
-                            cur = walk_pop(st, r);
-                            open_leaf();
+                        if (INSTANCES && phase == PHASE_INSTS) {
+                            // Instance::hit: into the instance's frame, then its set's three buffers
+                            WALK_CHECK(li < sc.n_insts, 2)
+                            const uint32_t gi = li++;
+                            const float4 *ip = sc.insts + 7 * (size_t)gi;
+                            const Affine inv = load_affine(ip);
+                            child = __float_as_uint(ip[6].x);
+                            WALK_CHECK(child < sc.n_sets, 3)
+                            st.push(cur, __uint_as_float(li));  // where to go on in the instance buffer
+                            st.push(REF_RETURN, 0.0f);
+                            const float t_min = r.t_min, t_max = r.t_max;
+                            r = make_trav_ray(xf_point(inv, r.o), xf_vector(inv, r.d), t_min, t_max);
+                            lane_plain = ray_is_plain(r);
+                            inst_code = (gi - set.insts.prim_first + 1u) << 2;
+                            phase = PHASE_CHILD;
+                            li = lend = 0u;  // the leaf of the instance buffer is set aside (its place is in the record)
+                            begin_buffer(sc.sets[child].tris);
+                        } else {
+                            const uint32_t type = phase & 3u;
+                            WALK_CHECK(li < (type == 0u ? sc.n_tris : (type == 1u ? sc.n_spheres : sc.n_quads)), 4)
+                            if (type == 0u) hit_prim<PT_PRIM_TRI>(sc, li, r, h, inst_code, tc);
+                            else if (type == 1u) hit_prim<PT_PRIM_SPHERE>(sc, li, r, h, inst_code, tc);
+                            else hit_prim<PT_PRIM_QUAD>(sc, li, r, h, inst_code, tc);
+                            li++;
+                            if (li == lend) {
+                                cur = walk_pop(st, r);
+                                open_leaf(0u);
+                            }
                         }
                     }
                 }
             }
-            // (C) nothing left in this buffer (its stack is empty): on to the next one
-            if (cur == REF_NONE) {
-                phase++;
-                if (phase == 1u) {
-                    node_base = set.spheres.wide_first;
-                    prim_base = set.spheres.prim_first;
-                    cur = walk_begin(set.spheres, r);
-                    open_leaf();
-                } else if (phase == 2u) {
-                    node_base = set.quads.wide_first;
-                    prim_base = set.quads.prim_first;
-                    cur = walk_begin(set.quads, r);
-                    open_leaf();
+            // (C) nothing left in this buffer: on to the next one, or out of the instance
+            if (INSTANCES && cur == REF_RETURN) {
+                WALK_CHECK(inst_code != 0u && phase >= PHASE_CHILD, 8)
+                if (phase < PHASE_CHILD + 2u) {
+                    phase++;
+                    const DevSet &cs = sc.sets[child];
+                    begin_buffer(phase == PHASE_CHILD + 1u ? cs.spheres : cs.quads);
+                } else {
+                    // back to the world frame and to the leaf of the instance buffer the lane came from
+                    uint32_t leaf_ref = REF_NONE;
+                    float next = 0.0f;
+                    st.pop(0, leaf_ref, next);  // the REF_RETURN record
+                    WALK_CHECK(leaf_ref == REF_RETURN, 9)
+                    leaf_ref = REF_NONE;
+                    st.pop(0, leaf_ref, next);  // (leaf of the instance buffer, next instance)
+                    WALK_CHECK((leaf_ref & WIDE_LEAF) && leaf_ref != REF_NONE && leaf_ref != REF_RETURN, 6)
+                    f3 o, d;
+                    reload(slot, o, d);
+                    const float t_min = r.t_min, t_max = r.t_max;
+                    r = make_trav_ray(o, d, t_min, t_max);
+                    lane_plain = ray_is_plain(r);
+                    inst_code = 0u;
+                    phase = PHASE_INSTS;
+                    node_base = set.insts.wide_first;
+                    prim_base = set.insts.prim_first;
+                    cur = leaf_ref;
+                    open_leaf(set.insts.prim_count);
+                    li = __float_as_uint(next);
+                    if (li >= lend) {
+                        cur = walk_pop(st, r);
+                        open_leaf(0u);
+                    }
                 }
+            } else if (cur == REF_NONE) {
+                // world level (inside an instance the bottom of the stack is REF_RETURN)
+                WALK_CHECK(inst_code == 0u && st.sp == 0 && !st.has_top, 7)
+                phase++;
+                if (phase == 1u) begin_buffer(set.spheres);
+                else if (phase == 2u) begin_buffer(set.quads);
+                else if (INSTANCES && phase == PHASE_INSTS) begin_buffer(set.insts);
+                else phase = PHASE_DONE;
             }
-            if (can_refill && __popcll(__ballot(phase < 3u)) < refill_below) break;
+            // lanes may have changed frame in this pass
+            if (INSTANCES) plain = sc.boxes_finite != 0u && __ballot(phase < PHASE_DONE && !lane_plain) == 0ull;
+            if (can_refill && __popcll(__ballot(phase < PHASE_DONE)) < refill_below) break;
         }
 
         // ---- finished rays leave
-        sink(phase == 3u, slot, r, h);
-        if (phase == 3u) phase = 4u;
+        sink(phase == PHASE_DONE, slot, r, h);
+        if (phase == PHASE_DONE) phase = PHASE_IDLE;
     }
 }
 

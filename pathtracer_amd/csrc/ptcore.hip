@@ -33,6 +33,9 @@ using namespace ptd;
 struct DevStats {
     unsigned long long rays_total, paths_total, extend_nonempty;
     unsigned long long node_tests, tri_tests, sphere_tests, quad_tests;
+    // PT_BOUNDS_CHECK build only: [0] out-of-range references caught, [1] lanes that gave up after too
+    // many passes, [2..7] state of the first such lane
+    unsigned long long bad_refs[8];
 };
 
 struct BatchParams {
@@ -241,24 +244,25 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
     flush_counters(COUNT, tc, stats);
 }
 
-// The same step with rays drawn by the waves as their lanes fall idle (dev_walk.h); this is
-// the form used for rendering whenever the scene's leaves fit the 64-byte node layout.
+// The whole of PrimitiveBuffer::hit with rays drawn by the waves as their lanes fall idle
+// (dev_walk.h); this is the form used for rendering whenever the scene's leaves fit the
+// 64-byte node layout.  INSTANCES: the world has an instance buffer.
 #ifdef PT_WALK_WAVES
 #define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
 #else
 #define WALK_OCCUPANCY
 #endif
-template <bool CLASSIFY>
+template <bool INSTANCES>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
     extend_prologue(ps, parity, n_chunks, stats);
     if (n_chunks == 0u) return;
-    if (CLASSIFY) shade_push_init();
+    shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     const uint32_t *queue = ps.ray_queue[parity];
-    walk_world_prims(
-        sc, n_chunks, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st,
+    walk_world<INSTANCES>(
+        sc, n_chunks, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = queue[i];
             if (slot == QUEUE_EMPTY) return false;
@@ -266,14 +270,19 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
             return true;
         },
+        [&](uint32_t slot, f3 &o, f3 &d) {
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            o = mk3(ro.x, ro.y, ro.z);
+            d = mk3(rd.x, rd.y, rd.z);
+        },
         [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
             if (done) {
                 ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
                 ps.hit2[slot] = h.code;
             }
-            if (CLASSIFY) classify(sc, ps, parity, background, done, slot, h.code, h.prim);
+            classify(sc, ps, parity, background, done, slot, h.code, h.prim);
         });
-    if (CLASSIFY) shade_push_close(ps);
+    shade_push_close(ps);
 }
 
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
@@ -473,17 +482,23 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
         ps.hit2[i] = h.code;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps, uint32_t n) {
+template <bool INSTANCES>
+__global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps, uint32_t n, DevStats *stats) {
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
-    walk_world_prims(
-        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK, &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st,
+    walk_world<INSTANCES>(
+        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK, &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = ps.ray_queue[0][i];
             if (slot == QUEUE_EMPTY) return false;
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
             return true;
+        },
+        [&](uint32_t slot, f3 &o, f3 &d) {
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            o = mk3(ro.x, ro.y, ro.z);
+            d = mk3(rd.x, rd.y, rd.z);
         },
         [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
             if (done) {
@@ -712,6 +727,16 @@ static int sync_all(pt_context *ctx) {
         ctx->extend_iv.clear();
     }
     HIP_TRY(ctx, hipGetLastError());
+#ifdef PT_BOUNDS_CHECK
+    unsigned long long bad[8];
+    HIP_TRY(ctx, hipMemcpy(bad, ctx->stats->bad_refs, sizeof bad, hipMemcpyDeviceToHost));
+    if (bad[0] || bad[1])
+        return fail(ctx, PT_ERR_STATE,
+                    "device checks: %llu bad references, %llu lanes gave up; first: check %llu phase %llu cur %#llx node_base %llu li %llu lend %llu "
+                    "inst %#llx prim_base %llu sp %llu top %llu slot %llu child %llu",
+                    bad[0], bad[1], bad[2] >> 32, bad[2] & 0xFFFFFFFFull, bad[3] & 0xFFFFFFFFull, bad[3] >> 32, bad[4] >> 32, bad[4] & 0xFFFFFFFFull,
+                    bad[5] & 0xFFFFFFFFull, bad[5] >> 32, bad[6] & 0xFFFFFFFFull, bad[6] >> 32, bad[7] & 0xFFFFFFFFull, bad[7] >> 32);
+#endif
     return PT_OK;
 }
 // Time zero for the event intervals of the profile.
@@ -1067,7 +1092,8 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     // an instance, those of the instance BVH above it
     uint32_t child_depth = 0;
     for (uint32_t k = 2; k < s->n_sets; k++) child_depth = std::max(child_depth, set_depth[k]);
-    ctx->stack_need = std::max(set_depth[0], world_inst_depth + child_depth) + 2u;
+    // + the newest entry kept in registers, + the two records an instance descent leaves on the stack
+    ctx->stack_need = std::max(set_depth[0], world_inst_depth + child_depth) + 4u;
     ctx->wide_ok = wide_ok;
     bool boxes_finite = true;
     for (uint32_t i = 0; i < s->n_nodes && boxes_finite; i++)
@@ -1126,6 +1152,12 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     d.n_materials = s->n_materials;
     d.n_light_total = sets[1].tris.prim_count + sets[1].spheres.prim_count + sets[1].quads.prim_count + sets[1].insts.prim_count;
     d.boxes_finite = boxes_finite ? 1u : 0u;
+    d.n_wide = (uint32_t)(wide.size() / 4);
+    d.n_tris = s->n_tris;
+    d.n_spheres = s->n_spheres;
+    d.n_quads = s->n_quads;
+    d.n_insts = s->n_instances;
+    d.n_sets = s->n_sets;
     ctx->scene = d;
     ctx->have_scene = true;
     // shade queues depend on which material types exist: drop path state so it is rebuilt
@@ -1233,12 +1265,8 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
     if (ctx->counters) {
         if (insts) { EXT(false, true, false); EXI(false, true); } else EXT(false, true, true);
     } else if (ctx->use_wide()) {
-        if (insts) {
-            hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
-            EXI(true, false);
-        } else {
-            hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
-        }
+        if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
+        else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
     } else {
         if (insts) { EXT(false, false, false); EXI(false, false); } else EXT(false, false, true);
     }
@@ -1467,8 +1495,8 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
         const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
         const bool insts = ctx->scene.world.insts.prim_count != 0;
         if (ctx->use_wide()) {
-            hipLaunchKernelGGL(k_trace_walk, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
-            if (insts) hipLaunchKernelGGL((k_trace_inst<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
+            else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
         } else {
             hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
             if (insts) hipLaunchKernelGGL((k_trace_inst<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
@@ -1481,7 +1509,7 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     (void)hipFree(d_rays);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
-    return PT_OK;
+    return sync_all(ctx);
 }
 
 int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples) {
@@ -1557,6 +1585,7 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
     out->tri_tests = ds.tri_tests;
     out->sphere_tests = ds.sphere_tests;
     out->quad_tests = ds.quad_tests;
+    out->bad_refs = ds.bad_refs[0] + ds.bad_refs[1];
     out->device_bytes = ctx->device_bytes;
     return PT_OK;
 }
