@@ -14,8 +14,7 @@
 //   PrimitiveBuffer::hit                  src/objects.rs:191-197 (triangles, spheres, quads, instances)
 //
 // Each lane keeps its traversal stack in LDS (one bank column per lane, so pushes and
-// pops never conflict); entries beyond LDS_LEVELS spill to a private array that real
-// scenes do not reach.
+// pops never conflict); entries beyond LDS_LEVELS go to a global overflow array.
 #pragma once
 #include "dev_queue.h"
 
@@ -262,20 +261,12 @@ __device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint3
 }
 
 // ---------------------------------------------------------------------------------------
-// Two traversals of one InnerPrimitiveBuffer.  Both visit leaves in the reference's order
-// and test a primitive only when the reference would.
-//
-// traverse_ref: the reference's loop verbatim over 32-byte nodes (one AABB per visit, the
-// far child is pushed untested and tested when popped).  Used when AABB / primitive tests
-// are being counted, and as the yardstick the wide form is checked against.
-//
-// traverse_wide: 64-byte nodes holding both children's boxes.  Both boxes are tested when
-// the parent is visited (nothing is intersected between that moment and the reference's own
-// test of the near child, so t_max is the same); a far child that passes is pushed with its
-// entry distance E and is dropped at pop time when t_max has shrunk below E, which is the
-// outcome of the reference's test at that moment (see slab_test_entry).  The root's own box
-// comes with the buffer descriptor.
-template <bool WIDE, class LeafFn>
+// The reference's loop verbatim over 32-byte nodes (InnerPrimitiveBuffer::traverse,
+// src/bvh.rs:725-797): one AABB per visit, near child first by the sign of the direction on
+// the split axis, the far child pushed untested and tested when popped.  Used when AABB /
+// primitive tests are being counted, when a scene does not fit the 64-byte node layout, and
+// as the yardstick the persistent-wave traversal (dev_walk.h) is checked against.
+template <class LeafFn>
 __device__ __forceinline__ void traverse(const DevScene &sc, const DevBuffer &buf, TravRay &r, LaneStack &st, TravCounters &tc,
                                          LeafFn &&leaf) {
     if (buf.prim_count == 0) return;
@@ -286,85 +277,43 @@ __device__ __forceinline__ void traverse(const DevScene &sc, const DevBuffer &bu
     }
     const bool neg_x = r.d.x < 0.0f, neg_y = r.d.y < 0.0f, neg_z = r.d.z < 0.0f;
     const int floor = st.enter();
-    if constexpr (!WIDE) {
-        const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
-        uint32_t cur = 0;
-        for (;;) {
-            const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
-            tc.nodes++;
-            bool descend = false;
-            if (slab_test(n0, n1, r)) {
-                const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
-                if (!(b & PT_NODE_LEAF)) {
-                    const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
-                    if (neg) {
-                        st.push(cur + 1, 0.0f);
-                        cur = a;
-                    } else {
-                        st.push(a, 0.0f);
-                        cur = cur + 1;
-                    }
-                    descend = true;
+    const float4 *nodes = sc.nodes + 2 * (size_t)buf.node_first;
+    uint32_t cur = 0;
+    for (;;) {
+        const float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+        tc.nodes++;
+        bool descend = false;
+        if (slab_test(n0, n1, r)) {
+            const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
+            if (!(b & PT_NODE_LEAF)) {
+                const bool neg = (b == 0) ? neg_x : ((b == 1) ? neg_y : neg_z);
+                if (neg) {
+                    st.push(cur + 1, 0.0f);
+                    cur = a;
                 } else {
-                    const uint32_t cnt = b & 0xFFFFu;
-#pragma unroll 1
-                    for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i);
+                    st.push(a, 0.0f);
+                    cur = cur + 1;
                 }
-            }
-            if (!descend) {
-                float e;
-                if (!st.pop(floor, cur, e)) break;
+                descend = true;
+            } else {
+                const uint32_t cnt = b & 0xFFFFu;
+#pragma unroll 1
+                for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i);
             }
         }
-    } else {
-        float e;
-        if (!slab_test_entry(buf.rmin[0], buf.rmin[1], buf.rmin[2], buf.rmax[0], buf.rmax[1], buf.rmax[2], r, e)) return;
-        const float4 *wide = sc.wide + 4 * (size_t)buf.wide_first;
-        uint32_t cur = buf.root_ref;
-        for (;;) {
-            bool descend = false;
-            if (!(cur & WIDE_LEAF)) {
-                const float4 a = wide[4 * cur], b = wide[4 * cur + 1], c = wide[4 * cur + 2], d = wide[4 * cur + 3];
-                float el, er;
-                const bool hl = slab_test_entry(a.x, a.y, a.z, a.w, b.x, b.y, r, el);
-                const bool hr = slab_test_entry(b.z, b.w, c.x, c.y, c.z, c.w, r, er);
-                const uint32_t lref = __float_as_uint(d.x), rref = __float_as_uint(d.y), axis = __float_as_uint(d.z);
-                const bool neg = (axis == 0) ? neg_x : ((axis == 1) ? neg_y : neg_z);
-                const uint32_t first = neg ? rref : lref, second = neg ? lref : rref;
-                const bool hf = neg ? hr : hl, hs = neg ? hl : hr;
-                const float es = neg ? el : er;
-                if (hf) {
-                    if (hs) st.push(second, es);
-                    cur = first;
-                    descend = true;
-                } else if (hs) {
-                    cur = second;
-                    descend = true;
-                }
-            } else {
-                const uint32_t cnt = (cur >> 24) & 0x7Fu, off = cur & 0xFFFFFFu;
-#pragma unroll 1
-                for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + off + i);
-            }
-            if (!descend) {
-                bool got;
-                for (;;) {
-                    got = st.pop(floor, cur, e);
-                    if (!got || !(r.t_max < e)) break;
-                }
-                if (!got) break;
-            }
+        if (!descend) {
+            float e;
+            if (!st.pop(floor, cur, e)) break;
         }
     }
 }
 
 // The triangle, sphere and quad buffers of one PrimitiveBuffer, in that order.
-template <bool WIDE>
 __device__ __forceinline__ void hit_set_prims(const DevScene &sc, const DevSet &set, TravRay &r, HitState &h,
                                               uint32_t inst_code, LaneStack &st, TravCounters &tc) {
-    traverse<WIDE>(sc, set.tris, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_TRI>(sc, g, r, h, inst_code, tc); });
-    traverse<WIDE>(sc, set.spheres, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_SPHERE>(sc, g, r, h, inst_code, tc); });
-    traverse<WIDE>(sc, set.quads, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_QUAD>(sc, g, r, h, inst_code, tc); });
+    traverse(sc, set.tris, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_TRI>(sc, g, r, h, inst_code, tc); });
+    traverse(sc, set.spheres, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_SPHERE>(sc, g, r, h, inst_code, tc); });
+    traverse(sc, set.quads, r, st, tc, [&](uint32_t g) { hit_prim<PT_PRIM_QUAD>(sc, g, r, h, inst_code, tc); });
 }
 
 __device__ __forceinline__ Affine load_affine(const float4 *p) {
@@ -378,7 +327,6 @@ __device__ __forceinline__ Affine load_affine(const float4 *p) {
 
 // Instance::hit: the ray is taken into the instance's frame without renormalising the
 // direction, so t is shared between the two frames.
-template <bool WIDE>
 __device__ __forceinline__ void hit_instance(const DevScene &sc, uint32_t gi, TravRay &r, HitState &h, LaneStack &st,
                                              TravCounters &tc) {
     const float4 *ip = sc.insts + 7 * (size_t)gi;
@@ -390,7 +338,7 @@ __device__ __forceinline__ void hit_instance(const DevScene &sc, uint32_t gi, Tr
     hl.u = hl.v = 0.0f;
     hl.prim = 0;
     const DevSet &set = sc.sets[child];
-    hit_set_prims<WIDE>(sc, set, local, hl, (gi - sc.world.insts.prim_first + 1u) << 2, st, tc);
+    hit_set_prims(sc, set, local, hl, (gi - sc.world.insts.prim_first + 1u) << 2, st, tc);
     if (hl.code != PTD_HIT_MISS) {
         h = hl;
         r.t_max = local.t_max;
@@ -402,16 +350,14 @@ __device__ __forceinline__ void hit_instance(const DevScene &sc, uint32_t gi, Tr
 // the instance buffer, which the reference also visits last, with t_max as the first part
 // left it.  On return r.t_max is the hit distance (or the incoming t_max on a miss) and h
 // identifies the primitive.
-template <bool WIDE>
 __device__ __forceinline__ void hit_world_prims(const DevScene &sc, TravRay &r, HitState &h, LaneStack &st, TravCounters &tc) {
     h.code = PTD_HIT_MISS;
     h.u = h.v = 0.0f;
     h.prim = 0;
-    hit_set_prims<WIDE>(sc, sc.world, r, h, 0u, st, tc);
+    hit_set_prims(sc, sc.world, r, h, 0u, st, tc);
 }
-template <bool WIDE>
 __device__ __forceinline__ void hit_world_insts(const DevScene &sc, TravRay &r, HitState &h, LaneStack &st, TravCounters &tc) {
-    traverse<WIDE>(sc, sc.world.insts, r, st, tc, [&](uint32_t gi) { hit_instance<WIDE>(sc, gi, r, h, st, tc); });
+    traverse(sc, sc.world.insts, r, st, tc, [&](uint32_t gi) { hit_instance(sc, gi, r, h, st, tc); });
 }
 
 }  // namespace ptd

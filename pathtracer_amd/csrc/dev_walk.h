@@ -2,9 +2,17 @@
 // world's triangle, sphere and quad buffers and, when INSTANCES, its instance buffer with
 // Instance::hit (src/objects.rs:384-401) into the instanced sets, on 64-byte two-box nodes.
 //
-// Every ray runs exactly the sequence of box and primitive tests of traverse<true> in
-// dev_traverse.h (hence of InnerPrimitiveBuffer::traverse, src/bvh.rs:725-797); what
-// changes is which lane runs which ray and when.  Rays are not bound to lanes in advance:
+// Nodes.  A 64-byte node holds both children's boxes.  Both are tested when the parent is
+// visited (nothing is intersected between that moment and the reference's own test of the
+// near child, so t_max is the same); a far child that passes is pushed with its entry
+// distance E and is dropped at pop time when t_max has shrunk below E, which is the outcome
+// of the reference's lazy test of that box at that moment (slab_test_entry in
+// dev_traverse.h).  The root's own box comes with the buffer descriptor.  Every ray
+// therefore visits the leaves InnerPrimitiveBuffer::traverse (src/bvh.rs:725-797) visits,
+// in its order, with its t_max, and tests the same primitives: ids and t are bit-identical
+// to traverse() in dev_traverse.h, ties included.
+//
+// Scheduling.  What changes is which lane runs which ray and when.  Rays are not bound to lanes in advance:
 // a wave claims pieces of the ray queue through an atomic cursor (a whole 256-entry chunk
 // per atomic when the queue is long, 64 entries when it is short, so that short queues
 // still spread over many waves), and deals the claimed entries to its idle lanes.  When

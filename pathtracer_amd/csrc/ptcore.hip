@@ -215,7 +215,7 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 // Closest hit among the world's triangles, spheres and quads for every ray of the current
 // queue (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
-template <bool WIDE, bool COUNT, bool CLASSIFY>
+template <bool COUNT, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
     extend_prologue(ps, parity, n_chunks, stats);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
         if (active) {
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            hit_world_prims<WIDE>(sc, r, h, st, tc);
+            hit_world_prims(sc, r, h, st, tc);
             ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
             ps.hit2[slot] = h.code;
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
 
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
 // continuing from the hit and t_max the first kernel left; then classification.
-template <bool WIDE, bool COUNT>
+template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
     shade_push_init();
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
             TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, h4.x);
             const uint32_t before = h.code;
             const float t_before = r.t_max;
-            hit_world_insts<WIDE>(sc, r, h, st, tc);
+            hit_world_insts(sc, r, h, st, tc);
             if (h.code != before || r.t_max != t_before || h.prim != __float_as_uint(h4.w)) {
                 ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
                 ps.hit2[slot] = h.code;
@@ -468,7 +468,6 @@ __global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathStat
 }
 
 // Closest hit for caller-supplied rays with their own [t_min, t_max]: the same two parts.
-template <bool WIDE>
 __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint32_t n) {
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
         const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
         TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
         HitState h;
-        hit_world_prims<WIDE>(sc, r, h, st, tc);
+        hit_world_prims(sc, r, h, st, tc);
         ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
         ps.hit2[i] = h.code;
     }
@@ -507,7 +506,6 @@ __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps,
             }
         });
 }
-template <bool WIDE>
 __global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps, uint32_t n) {
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
@@ -520,7 +518,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps,
         h.prim = __float_as_uint(h4.w);
         h.code = ps.hit2[i];
         TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, h4.x);
-        hit_world_insts<WIDE>(sc, r, h, st, tc);
+        hit_world_insts(sc, r, h, st, tc);
         ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
         ps.hit2[i] = h.code;
     }
@@ -1260,15 +1258,15 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
     const dim3 g(grid), b(BLOCK);
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
-#define EXT(W, C, K) hipLaunchKernelGGL((k_extend<W, C, K>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
-#define EXI(W, C) hipLaunchKernelGGL((k_extend_inst<W, C>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
+#define EXT(C, K) hipLaunchKernelGGL((k_extend<C, K>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
+#define EXI(C) hipLaunchKernelGGL((k_extend_inst<C>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
     if (ctx->counters) {
-        if (insts) { EXT(false, true, false); EXI(false, true); } else EXT(false, true, true);
+        if (insts) { EXT(true, false); EXI(true); } else EXT(true, true);
     } else if (ctx->use_wide()) {
         if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
         else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
     } else {
-        if (insts) { EXT(false, false, false); EXI(false, false); } else EXT(false, false, true);
+        if (insts) { EXT(false, false); EXI(false); } else EXT(false, true);
     }
 #undef EXT
 #undef EXI
@@ -1498,8 +1496,8 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
             if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
             else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
         } else {
-            hipLaunchKernelGGL((k_trace<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
-            if (insts) hipLaunchKernelGGL((k_trace_inst<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            hipLaunchKernelGGL(k_trace, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL(k_trace_inst, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         }
         hipLaunchKernelGGL(k_trace_out, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, pp.ps, (uint32_t)n, d_out);
         e = hipMemcpyAsync(out, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost, st);
