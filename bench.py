@@ -188,7 +188,7 @@ def main():
                                    + (" (procedural stand-in for mitsuba_smooth.obj, Disney + Lambertian + emitter)" if args.scene == "knob" else "")
                                    + f", {S} full-frame strata per step per GPU",
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce"},
-            "roofline": {"bound": "hbm", "kernel": "k_extend", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_extend_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
                          "launches": st["extend_launches"], "busy_ms": st["extend_busy_ms"],
