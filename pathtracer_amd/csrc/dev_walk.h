@@ -41,12 +41,13 @@
 namespace ptd {
 
 // Stack / `cur` values that are not node references.  None can be a leaf reference: all
-// decode to 127 primitives at an offset of at least 2^24 - 3, past the largest offset a
+// decode to 127 primitives at an offset of at least 2^24 - 4, past the largest offset a
 // leaf may have.
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;    // nothing pending: the stack is empty
 constexpr uint32_t REF_LINEAR = 0xFFFFFFFEu;  // buffer without a BVH: all primitives in order (src/bvh.rs:726-737)
 constexpr uint32_t REF_RETURN = 0xFFFFFFFDu;  // bottom of an instance's part of the stack; the record below it
                                               // holds (leaf of the instance buffer in progress, next instance)
+constexpr uint32_t REF_POP = 0xFFFFFFFCu;     // `cur` only: the lane needs the next entry of its stack
 constexpr uint32_t PHASE_INSTS = 3u, PHASE_CHILD = 4u, PHASE_DONE = 7u, PHASE_IDLE = 8u;
 
 // First node of a buffer for ray r: the buffer's own early-outs and the root's box.
@@ -136,7 +137,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_chunks
 #endif
     // [li, lend) of the leaf in `cur`; `count` = primitives of the buffer in progress (for REF_LINEAR)
     auto open_leaf = [&](uint32_t count) {
-        if ((cur & WIDE_LEAF) && cur < REF_RETURN) {
+        if ((cur & WIDE_LEAF) && cur < REF_POP) {
             li = prim_base + (cur & 0xFFFFFFu);
             lend = li + ((cur >> 24) & 0x7Fu);
         } else if (cur == REF_LINEAR) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_chunks
                 } else if (hf) {
                     cur = far_ref;
                 } else {
-                    cur = walk_pop(st, r);
+                    cur = REF_POP;
                 }
                 open_leaf(0u);  // a reference out of a node or off the stack is never REF_LINEAR
             }
@@ -264,13 +265,15 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_chunks
                             else if (type == 1u) hit_prim<PT_PRIM_SPHERE>(sc, li, r, h, inst_code, tc);
                             else hit_prim<PT_PRIM_QUAD>(sc, li, r, h, inst_code, tc);
                             li++;
-                            if (li == lend) {
-                                cur = walk_pop(st, r);
-                                open_leaf(0u);
-                            }
+                            if (li == lend) cur = REF_POP;
                         }
                     }
                 }
+            }
+            // (P) the one place where the stack is popped
+            if (cur == REF_POP) {
+                cur = walk_pop(st, r);
+                open_leaf(0u);
             }
             // (C) nothing left in this buffer: on to the next one, or out of the instance
             if (INSTANCES && cur == REF_RETURN) {
@@ -300,10 +303,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_chunks
                     cur = leaf_ref;
                     open_leaf(set.insts.prim_count);
                     li = __float_as_uint(next);
-                    if (li >= lend) {
-                        cur = walk_pop(st, r);
-                        open_leaf(0u);
-                    }
+                    if (li >= lend) cur = REF_POP;
                 }
             } else if (cur == REF_NONE) {
                 // world level (inside an instance the bottom of the stack is REF_RETURN)
