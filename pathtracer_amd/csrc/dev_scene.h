@@ -98,6 +98,7 @@ constexpr uint32_t CTL_STRIDE = 64;  // in 32-bit words
 constexpr uint32_t CTL_RAY_CHUNKS = 0;    // +parity: chunks in ray queue [parity]
 constexpr uint32_t CTL_RAY_CURSOR = 2;    // +parity: 64-entry pieces of ray queue [parity] handed out so far
 constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material queue [queue]
+constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
 constexpr uint32_t CTL_WORDS = (4 + 2 * MAX_QUEUES) * CTL_STRIDE;
 
 // Per-path state, indexed by slot = pixel * strata_in_batch + (stratum - batch_first_stratum).
@@ -111,6 +112,7 @@ struct PathState {
     uint32_t *ray_queue[2];             // max_chunks * QUEUE_CHUNK entries each
     uint32_t *shade_queue[MAX_QUEUES];  // likewise; only the queues of material types in use exist
     uint32_t *ctl;                      // CTL_WORDS control words
+    uint32_t *bounce_rays;              // [BOUNCE_PROFILE_LEN] rays traced at each bounce of the batch ([0] unused)
     uint32_t max_chunks;
     uint32_t n_queues;
     uint2 *overflow;           // traversal stack levels beyond LDS: [level][overflow_stride]

@@ -193,8 +193,9 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
 
 // What every closest-hit kernel does first: clear the control words the shade kernels of
 // this bounce will fill, and count the launch.
-__device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t parity, uint32_t n_chunks, DevStats *stats) {
+__device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bounce, uint32_t n_chunks, DevStats *stats) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t parity = bounce & 1u;
         ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
         ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
         if (n_chunks) atomicAdd(&stats->extend_nonempty, 1ull);
@@ -216,9 +217,10 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 // queue (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
 template <bool COUNT, bool CLASSIFY>
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
+    const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    extend_prologue(ps, parity, n_chunks, stats);
+    extend_prologue(ps, bounce, n_chunks, stats);
     if (CLASSIFY) shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
@@ -253,9 +255,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
 #define WALK_OCCUPANCY
 #endif
 template <bool INSTANCES>
-__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
+    const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    extend_prologue(ps, parity, n_chunks, stats);
+    extend_prologue(ps, bounce, n_chunks, stats);
     if (n_chunks == 0u) return;
     shade_push_init();
     LaneStack st;
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
 // continuing from the hit and t_max the first kernel left; then classification.
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t parity, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
+    const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
     shade_push_init();
     LaneStack st;
@@ -326,7 +330,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
 // One path vertex for every path whose hit has a material of type MT: the body of
 // Camera::ray_color after the hit (src/camera.rs:286-369), in multiplicative form.
 template <int MT>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t parity, uint32_t q, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
+    const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
     const uint32_t *queue = ps.shade_queue[q];
@@ -414,7 +419,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
     }
     if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
         wave_push_close(out, ps.ray_queue[parity ^ 1u]);
-        if (survivors && lane_id() == 0u) atomicAdd(&stats->rays_total, (unsigned long long)survivors);  // rays of the next bounce
+        if (survivors && lane_id() == 0u) {  // rays of the next bounce
+            atomicAdd(&stats->rays_total, (unsigned long long)survivors);
+            if (bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
+        }
     }
 }
 
@@ -596,6 +604,9 @@ struct pt_context {
         uint64_t capacity = 0;
         hipEvent_t accumulated[2] = {nullptr, nullptr};  // recorded after a batch's k_accumulate, alternately
         uint64_t batches = 0;                            // batches enqueued on this pipe so far
+        uint32_t *host_chunks[2] = {nullptr, nullptr};   // pinned: rays per bounce of the batches before
+        uint32_t host_chunks_depth[2] = {0, 0};          // bounces recorded in each (0: nothing yet)
+        uint32_t host_paths[2] = {0, 0};                 // paths of the batch each belongs to
         // profiling: raygen, per-bounce extend/shade, accumulate; two sets used alternately so that
         // reading one back never waits for the batch just enqueued
         std::vector<hipEvent_t> events[2];
@@ -606,6 +617,10 @@ struct pt_context {
     int n_pipes = 4;
     uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
     hipEvent_t last_accumulated = nullptr;  // of the most recent batch: the next k_accumulate waits for it
+    // Rays per bounce of the most recent finished batch ([0] = its paths): launches of later batches are
+    // sized from it (any size is correct, the kernels loop over their queues; this only avoids
+    // dispatching thousands of workgroups that find nothing to do in the thin late bounces).
+    std::vector<uint32_t> bounce_profile;
     DevStats *stats = nullptr;
 
     // profiling
@@ -687,6 +702,10 @@ static void destroy_pipes(pt_context *ctx) {
             if (ev) (void)hipEventDestroy(ev);
             ev = nullptr;
         }
+        for (auto &hc : pp.host_chunks) {
+            if (hc) (void)hipHostFree(hc);
+            hc = nullptr;
+        }
         if (pp.stream) (void)hipStreamDestroy(pp.stream);
         pp.stream = nullptr;
     }
@@ -697,6 +716,12 @@ static void destroy_pipes(pt_context *ctx) {
 static void sync_pipes(pt_context *ctx) {
     for (auto &pp : ctx->pipes)
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
+}
+// What earlier batches looked like says nothing about the next ones (new scene, camera or sampling).
+static void forget_bounce_profile(pt_context *ctx) {
+    sync_pipes(ctx);
+    ctx->bounce_profile.clear();
+    for (auto &pp : ctx->pipes) pp.host_chunks_depth[0] = pp.host_chunks_depth[1] = 0;
 }
 
 // The entry points below have C linkage through their declarations in ptcore.h.
@@ -777,6 +802,7 @@ int pt_create(int device, pt_context **out) {
     for (int i = 0; i < pt_context::MAX_PIPES && e == hipSuccess; i++) {
         if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated[k], hipEventDisableTiming);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc((void **)&ctx->pipes[i].host_chunks[k], BOUNCE_PROFILE_LEN * sizeof(uint32_t), hipHostMallocDefault);
     }
     void *p = nullptr;
     if (e != hipSuccess || (e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
@@ -810,6 +836,7 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_BSDF_SAMPLE_PROBABILITY:
             if (!(value >= 0.0 && value <= 1.0)) return fail(ctx, PT_ERR_INVALID, "bsdf sample probability must be in [0,1]");
             ctx->bsdf_prob = (float)value;
+            forget_bounce_profile(ctx);
             return PT_OK;
         case PT_OPT_MAX_PATHS:
             if (!(value >= 1.0 && value <= 4.0e9)) return fail(ctx, PT_ERR_INVALID, "max paths out of range");
@@ -1025,7 +1052,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     mark(s->quad_mat, s->n_quads);
 
     // ---- build device images
-    sync_pipes(ctx);
+    forget_bounce_profile(ctx);
     free_pool(ctx, ctx->scene_allocs);
     ctx->have_scene = false;
     DevScene d{};
@@ -1187,7 +1214,7 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
     d.inv_sqrt_spp = c->inv_sqrt_spp;
     d.max_depth = c->max_depth;
     d.background = v(c->background);
-    sync_pipes(ctx);
+    forget_bounce_profile(ctx);
     const uint64_t npix = (uint64_t)d.width * d.height;
     if (!ctx->have_camera || (uint64_t)ctx->cam.width * ctx->cam.height != npix) {
         if (ctx->accum) (void)hipFree(ctx->accum);
@@ -1232,6 +1259,7 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
     // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
     ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
     const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
@@ -1254,17 +1282,17 @@ static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
 }
 
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
-static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t parity) {
+static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce) {
     const dim3 g(grid), b(BLOCK);
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
-#define EXT(C, K) hipLaunchKernelGGL((k_extend<C, K>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
-#define EXI(C) hipLaunchKernelGGL((k_extend_inst<C>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats)
+#define EXT(C, K) hipLaunchKernelGGL((k_extend<C, K>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats)
+#define EXI(C) hipLaunchKernelGGL((k_extend_inst<C>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats)
     if (ctx->counters) {
         if (insts) { EXT(true, false); EXI(true); } else EXT(true, true);
     } else if (ctx->use_wide()) {
-        if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
-        else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, parity, bg, ctx->stats);
+        if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats);
+        else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats);
     } else {
         if (insts) { EXT(false, false); EXI(false); } else EXT(false, true);
     }
@@ -1278,11 +1306,11 @@ struct ShadeLaunch {
     const PathState *ps;
     int grid;
     const BatchParams *bp;
-    uint32_t parity, q;
+    uint32_t bounce, q;
 };
 template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
-    hipLaunchKernelGGL(k_shade<MT>, dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.parity, l.q, l.ctx->stats);
+    hipLaunchKernelGGL(k_shade<MT>, dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats);
 }
 static void launch_shade_type(int type, const ShadeLaunch &l) {
     switch (type) {
@@ -1343,6 +1371,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->bsdf_prob};
     hipStream_t st = pp.stream;
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(pp.ps.bounce_rays, 0, BOUNCE_PROFILE_LEN * sizeof(uint32_t), st));
     pp.ps.n_slots = (uint32_t)n_slots;
     pp.ps.refill_below = ctx->refill_below;
     pp.ps.leaf_batch = ctx->leaf_batch;
@@ -1355,10 +1384,18 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     const int grid = grid_fixed(ctx, n_slots), grid_shade = grid_fixed(ctx, n_slots, ctx->shade_blocks_per_cu);
     const uint32_t depth = ctx->cam.max_depth;
     for (uint32_t b = 0; b < depth; b++) {
-        const uint32_t parity = b & 1u;
-        launch_extend(ctx, st, grid, ps, parity);
+        // one lane per ray seen at this bounce last time (scaled to this batch), twice that for slack
+        int g_ext = grid, g_sh = grid_shade;
+        if (b > 0 && b < ctx->bounce_profile.size() && ctx->bounce_profile[0] != 0u) {
+            const double scale = (double)n_slots / (double)ctx->bounce_profile[0];
+            const uint64_t rays = (uint64_t)((double)ctx->bounce_profile[b] * scale) + 1u;
+            const int want = (int)std::min<uint64_t>((rays + BLOCK - 1) / BLOCK * 2u + 8u, 1u << 30);
+            g_ext = std::min(grid, (want + 7) / 8 * 8);
+            g_sh = std::min(grid_shade, (want + 7) / 8 * 8);
+        }
+        launch_extend(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &bp, parity, q});
+        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, q});
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1393,7 +1430,14 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         const uint32_t k = std::min(per_batch, stratum_end - s);
         // the host runs at most two batches ahead of each pipe
         hipEvent_t done = pp.accumulated[pp.batches & 1u];
-        if (pp.batches >= 2) HIP_TRY(ctx, hipEventSynchronize(done));
+        if (pp.batches >= 2) {
+            HIP_TRY(ctx, hipEventSynchronize(done));
+            const uint32_t have = pp.host_chunks_depth[pp.batches & 1u];
+            if (have) {
+                ctx->bounce_profile.assign(pp.host_chunks[pp.batches & 1u], pp.host_chunks[pp.batches & 1u] + have);
+                ctx->bounce_profile[0] = pp.host_paths[pp.batches & 1u];  // bounce 0 traces every path of the batch
+            }
+        }
         if ((rc = run_batch(ctx, pp, s, k, seed))) return rc;
         if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(pp.stream, ctx->last_accumulated, 0));
         const size_t ev = 2 + 2 * (size_t)ctx->cam.max_depth;
@@ -1402,6 +1446,12 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         if (ctx->profile) {
             (void)hipEventRecord(get_event(pp, ev + 1), pp.stream);
             pp.events_pending[pp.batches & 1u] = ctx->cam.max_depth;
+        }
+        {
+            const uint32_t n_b = std::min<uint32_t>(ctx->cam.max_depth, BOUNCE_PROFILE_LEN);
+            HIP_TRY(ctx, hipMemcpyAsync(pp.host_chunks[pp.batches & 1u], pp.ps.bounce_rays, n_b * sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
+            pp.host_chunks_depth[pp.batches & 1u] = n_b;
+            pp.host_paths[pp.batches & 1u] = (uint32_t)((uint64_t)npix * k);
         }
         HIP_TRY(ctx, hipEventRecord(done, pp.stream));
         ctx->last_accumulated = done;
