@@ -149,6 +149,7 @@ typedef struct pt_stats {
     double shade_ms;
     double other_ms;
     double render_ms;         /* host wall time inside pt_render */
+    double host_wait_ms;      /* the part of it spent waiting for the device (pt_render runs at most two batches ahead per pipe) */
     /* traversal work, only counted with PT_OPT_COUNTERS: */
     uint64_t node_tests, tri_tests, sphere_tests, quad_tests;
     uint64_t device_bytes;    /* device memory held by the context */
@@ -164,7 +165,10 @@ enum {
     PT_OPT_PIPES = 5,                   /* batches of one render call in flight at once, each on its own stream; 1..8, default 4 */
     PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 24 */
     PT_OPT_LEAF_BATCH = 7,              /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 8 */
-    PT_OPT_BLOCKS_PER_CU = 8            /* resident workgroups per CU of the traversal kernels; 1..5, default 4 */
+    PT_OPT_BLOCKS_PER_CU = 8,           /* resident workgroups per CU of the traversal kernels; 1..5, default 4 */
+    PT_OPT_TAIL_BELOW = 9               /* once a bounce is expected to carry fewer rays than this, one launch finishes the
+                                           batch instead of per-bounce launches; 0 = never (default:
+                                           measured no faster on the benchmark scenes) */
 };
 
 typedef struct pt_context pt_context;

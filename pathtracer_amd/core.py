@@ -21,7 +21,7 @@ _host: Optional[C.CDLL] = None
 
 PT_NODE_LEAF = 0x80000000
 (PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS, PT_OPT_TRAVERSAL, PT_OPT_PIPES,
- PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_BLOCKS_PER_CU) = range(9)
+ PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_BLOCKS_PER_CU, PT_OPT_TAIL_BELOW) = range(10)
 
 
 class PtError(RuntimeError):
@@ -76,7 +76,7 @@ class pt_hit(C.Structure):
 
 class pt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
-                ("extend_busy_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double), ("render_ms", C.c_double), ("node_tests", C.c_uint64),
+                ("extend_busy_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double), ("render_ms", C.c_double), ("host_wait_ms", C.c_double), ("node_tests", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("quad_tests", C.c_uint64), ("device_bytes", C.c_uint64),
                 ("bad_refs", C.c_uint64)]
 

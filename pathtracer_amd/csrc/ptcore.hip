@@ -327,8 +327,83 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
     flush_counters(COUNT, tc, stats);
 }
 
-// One path vertex for every path whose hit has a material of type MT: the body of
-// Camera::ray_color after the hit (src/camera.rs:286-369), in multiplicative form.
+// One path vertex: the body of Camera::ray_color after the hit (src/camera.rs:286-369), in
+// multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
+// type MT.  Returns true when the path goes on: its next ray is then in ps.ray_o / ps.ray_d.
+template <int MT>
+__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot) {
+    const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
+    const uint32_t code = ps.hit2[slot];
+    const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+    f3 beta = mk3(b4.x, b4.y, b4.z);
+    uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
+    const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code);
+    const DevMaterial m = sc.mats[s.material];
+    if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
+        // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
+        f3 e = mk3(0.0f, 0.0f, 0.0f);
+        if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v);
+        ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
+    } else {
+        uint32_t pixel, stratum;
+        slot_to_sample(bp, slot, pixel, stratum);
+        Rng rng;
+        rng.init(bp.seed_mixed, pixel, stratum, __float_as_uint(ro4.w));
+        const Onb surface = make_onb(s.normal);
+        const f3 w_out = -normalize(to_local(surface, rd));
+        f3 w_in_world;
+        bool go_on = true;
+        if constexpr (MT == PTS_MAT_METAL || MT == PTS_MAT_DIELECTRIC) {
+            // purely specular: no pdf, no roulette (camera.rs:298-313)
+            const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
+            const f3 attenuation = mat_eval<MT>(sc, m, w_out, w_in, s);
+            w_in_world = to_world(surface, w_in);
+            beta = cmul(beta, attenuation);
+        } else {
+            // mixture of BSDF sampling and light sampling (camera.rs:317-357)
+            f3 w_in;
+            bool is_bsdf;
+            if (rng.gen_bool(bp.bsdf_prob)) {
+                w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
+                is_bsdf = true;
+                w_in_world = to_world(surface, w_in);
+            } else {
+                const f3 ls = light_sample(sc, rng, s.p);
+                w_in = normalize(to_local(surface, ls));
+                is_bsdf = false;
+                w_in_world = ls;
+            }
+            if (!is_bsdf) depth = 2u;
+            const float scatter_pdf = mat_pdf<MT>(m, w_out, w_in, s);
+            const float l_pdf = light_pdf(sc, s.p, w_in_world);
+            const float pdf = bp.bsdf_prob * scatter_pdf + (1.0f - bp.bsdf_prob) * l_pdf;
+            const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
+            const float cosv = fabsf(w_in.y);
+            const f3 throughput = (bsdf * cosv) / pdf;
+            const float weight = !is_bsdf ? 0.0f : 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
+            if (weight != weight || rng.gen_bool(weight)) {
+                go_on = false;  // returns Color::gray(0): contrib stays zero
+            } else {
+                beta = cmul(beta, throughput / (1.0f - weight));
+            }
+        }
+        if (go_on) {
+            depth -= 1u;
+            if (depth == 0u) {
+                // the next ray_color call returns zeros without tracing (camera.rs:271-273)
+                ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
+            } else {
+                ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
+                ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
+                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
 template <int MT>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
@@ -340,78 +415,8 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
     uint32_t survivors = 0u;
     const PieceWalk pw = piece_walk(n_chunks);
     for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        bool alive = false;
         const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        if (slot != QUEUE_EMPTY) {
-            const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
-            const uint32_t code = ps.hit2[slot];
-            const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
-            f3 beta = mk3(b4.x, b4.y, b4.z);
-            uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
-            const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code);
-            const DevMaterial m = sc.mats[s.material];
-            if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
-                // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
-                f3 e = mk3(0.0f, 0.0f, 0.0f);
-                if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v);
-                ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
-            } else {
-                uint32_t pixel, stratum;
-                slot_to_sample(bp, slot, pixel, stratum);
-                Rng rng;
-                rng.init(bp.seed_mixed, pixel, stratum, __float_as_uint(ro4.w));
-                const Onb surface = make_onb(s.normal);
-                const f3 w_out = -normalize(to_local(surface, rd));
-                f3 w_in_world;
-                bool go_on = true;
-                if constexpr (MT == PTS_MAT_METAL || MT == PTS_MAT_DIELECTRIC) {
-                    // purely specular: no pdf, no roulette (camera.rs:298-313)
-                    const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
-                    const f3 attenuation = mat_eval<MT>(sc, m, w_out, w_in, s);
-                    w_in_world = to_world(surface, w_in);
-                    beta = cmul(beta, attenuation);
-                } else {
-                    // mixture of BSDF sampling and light sampling (camera.rs:317-357)
-                    f3 w_in;
-                    bool is_bsdf;
-                    if (rng.gen_bool(bp.bsdf_prob)) {
-                        w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
-                        is_bsdf = true;
-                        w_in_world = to_world(surface, w_in);
-                    } else {
-                        const f3 ls = light_sample(sc, rng, s.p);
-                        w_in = normalize(to_local(surface, ls));
-                        is_bsdf = false;
-                        w_in_world = ls;
-                    }
-                    if (!is_bsdf) depth = 2u;
-                    const float scatter_pdf = mat_pdf<MT>(m, w_out, w_in, s);
-                    const float l_pdf = light_pdf(sc, s.p, w_in_world);
-                    const float pdf = bp.bsdf_prob * scatter_pdf + (1.0f - bp.bsdf_prob) * l_pdf;
-                    const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
-                    const float cosv = fabsf(w_in.y);
-                    const f3 throughput = (bsdf * cosv) / pdf;
-                    const float weight = !is_bsdf ? 0.0f : 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
-                    if (weight != weight || rng.gen_bool(weight)) {
-                        go_on = false;  // returns Color::gray(0): contrib stays zero
-                    } else {
-                        beta = cmul(beta, throughput / (1.0f - weight));
-                    }
-                }
-                if (go_on) {
-                    depth -= 1u;
-                    if (depth == 0u) {
-                        // the next ray_color call returns zeros without tracing (camera.rs:271-273)
-                        ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
-                    } else {
-                        ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
-                        ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
-                        ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
-                        alive = true;
-                    }
-                }
-            }
-        }
+        const bool alive = slot != QUEUE_EMPTY && shade_vertex<MT>(sc, ps, bp, slot);
         if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
             survivors += (uint32_t)__popcll(__ballot(alive));
             wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
@@ -424,6 +429,65 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
             if (bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
         }
     }
+}
+
+// Everything that is left of a batch from bounce `bounce` on, in one launch: each lane takes a
+// path of the ray queue and alternates closest hit (the reference-order loop) and shade_vertex
+// until the path ends.  Used where a batch has thinned to a few thousand paths: per-bounce
+// launches then cost more in launch latency than the work they carry, and this also covers
+// however many bounces remain without the host having to know.  The functions are the ones the
+// per-bounce kernels call, so every path gets the same arithmetic.
+__global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, f3 background, DevStats *stats) {
+    const uint32_t parity = bounce & 1u;
+    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    TravCounters tc{0, 0, 0, 0};
+    const uint32_t *queue = ps.ray_queue[parity];
+    const bool insts = sc.world.insts.prim_count != 0u;
+    uint32_t traced = 0u;  // rays beyond the ones the queue held (those are already counted)
+    const PieceWalk pw = piece_walk(n_chunks);
+    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
+        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
+        if (slot == QUEUE_EMPTY) continue;
+        for (;;) {
+            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            HitState h;
+            hit_world_prims(sc, r, h, st, tc);
+            if (insts) hit_world_insts(sc, r, h, st, tc);
+            int32_t mat = -1;
+            if (h.code != PTD_HIT_MISS) {
+                const uint32_t type = h.code & 3u;
+                mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
+            }
+            if (mat < 0) {  // src/camera.rs:371, :277-283
+                const float4 b = ps.beta[slot];
+                const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
+                ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+                break;
+            }
+            ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+            ps.hit2[slot] = h.code;
+            bool alive = false;
+            switch (sc.mats[mat].type) {
+                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN>(sc, ps, bp, slot); break;
+                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL>(sc, ps, bp, slot); break;
+                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC>(sc, ps, bp, slot); break;
+                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT>(sc, ps, bp, slot); break;
+                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY>(sc, ps, bp, slot); break;
+                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE>(sc, ps, bp, slot); break;
+                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL>(sc, ps, bp, slot); break;
+                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS>(sc, ps, bp, slot); break;
+                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT>(sc, ps, bp, slot); break;
+                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN>(sc, ps, bp, slot); break;
+                default: break;
+            }
+            if (!alive) break;
+            traced++;
+        }
+    }
+    if (traced) atomicAdd(&stats->rays_total, (unsigned long long)traced);
 }
 
 // `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).
@@ -579,6 +643,7 @@ struct pt_context {
     int blocks_per_cu = 4;
 #endif
     int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
+    int tail_below = 0;  // rays under which the rest of a batch goes to one launch (0: never)
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -627,6 +692,9 @@ struct pt_context {
     hipEvent_t epoch = nullptr;                      // time zero of the current render call
     std::vector<std::pair<float, float>> extend_iv;  // (start, end) of its closest-hit launches, ms since epoch
     double extend_busy_ms = 0;                       // time during which at least one closest-hit launch was running
+    std::vector<double> bounce_extend_ms, bounce_shade_ms;  // per bounce, summed over batches (profiling)
+    uint64_t profiled_batches = 0;
+    double host_wait_ms = 0;  // part of render_ms spent waiting so as not to run too far ahead of the device
     double extend_ms = 0, shade_ms = 0, other_ms = 0, render_ms = 0;
     uint64_t device_bytes = 0;
 };
@@ -867,6 +935,10 @@ int pt_set_option(pt_context *ctx, int key, double value) {
                 free_pool(ctx, pp.allocs);
                 pp.capacity = 0;
             }
+            return PT_OK;
+        case PT_OPT_TAIL_BELOW:
+            if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "tail threshold out of range");
+            ctx->tail_below = (int)value;
             return PT_OK;
         case PT_OPT_LEAF_BATCH:
             if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "leaf batch must be in [1,64]");
@@ -1347,11 +1419,18 @@ static void harvest_set(pt_context *ctx, pt_context::Pipe &pp, int which) {
     for (uint32_t b = 0; b < depth; b++) {
         (void)hipEventElapsedTime(&ms, evs[1 + 2 * b], evs[2 + 2 * b]);
         ctx->extend_ms += ms;
+        if (ctx->bounce_extend_ms.size() <= b) {
+            ctx->bounce_extend_ms.resize(b + 1, 0.0);
+            ctx->bounce_shade_ms.resize(b + 1, 0.0);
+        }
+        ctx->bounce_extend_ms[b] += ms;
         float since = 0;
         if (hipEventElapsedTime(&since, ctx->epoch, evs[1 + 2 * b]) == hipSuccess) ctx->extend_iv.push_back({since, since + ms});
         (void)hipEventElapsedTime(&ms, evs[2 + 2 * b], evs[3 + 2 * b]);
         ctx->shade_ms += ms;
+        ctx->bounce_shade_ms[b] += ms;
     }
+    ctx->profiled_batches++;
     (void)hipEventElapsedTime(&ms, evs[last - 1], evs[last]);
     ctx->other_ms += ms;
 }
@@ -1362,7 +1441,8 @@ static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp) {
 
 // Enqueues one batch (strata [first, first + k)) on a pipe: every bounce, no host wait.
 // Radiance is left in the pipe's ps.contrib.
-static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint32_t k, uint64_t seed) {
+// *bounces_out: bounces that have their own pair of profiling events (the tail launch counts as one).
+static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint32_t k, uint64_t seed, uint32_t *bounces_out = nullptr) {
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
     const uint64_t n_slots = (uint64_t)npix * k;
     harvest_set(ctx, pp, (int)(pp.batches & 1u));  // the set this batch is about to record into
@@ -1383,21 +1463,46 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     const int grid = grid_fixed(ctx, n_slots), grid_shade = grid_fixed(ctx, n_slots, ctx->shade_blocks_per_cu);
     const uint32_t depth = ctx->cam.max_depth;
-    for (uint32_t b = 0; b < depth; b++) {
-        // one lane per ray seen at this bounce last time (scaled to this batch), twice that for slack
+    // Rays expected at bounce b of this batch, from the most recent finished batch (0: unknown).
+    auto expected = [&](uint32_t b) -> uint64_t {
+        if (b == 0 || b >= ctx->bounce_profile.size() || ctx->bounce_profile[0] == 0u) return 0;
+        return (uint64_t)((double)ctx->bounce_profile[b] * ((double)n_slots / (double)ctx->bounce_profile[0])) + 1u;
+    };
+    // From the first bounce expected to carry fewer than tail_below rays, one launch finishes the batch.
+    uint32_t tail_from = depth;
+    if (ctx->tail_below > 0 && !ctx->counters)
+        for (uint32_t b = 1; b < depth; b++) {
+            const uint64_t e = expected(b);
+            if (e == 0) break;
+            if (e < (uint64_t)ctx->tail_below) {
+                tail_from = b;
+                break;
+            }
+        }
+    uint32_t bounces = 0;
+    for (uint32_t b = 0; b < depth; b++, bounces++) {
+        // one lane per expected ray, twice that for slack (any size is correct: the kernels loop over their queues)
         int g_ext = grid, g_sh = grid_shade;
-        if (b > 0 && b < ctx->bounce_profile.size() && ctx->bounce_profile[0] != 0u) {
-            const double scale = (double)n_slots / (double)ctx->bounce_profile[0];
-            const uint64_t rays = (uint64_t)((double)ctx->bounce_profile[b] * scale) + 1u;
+        if (const uint64_t rays = expected(b)) {
             const int want = (int)std::min<uint64_t>((rays + BLOCK - 1) / BLOCK * 2u + 8u, 1u << 30);
             g_ext = std::min(grid, (want + 7) / 8 * 8);
             g_sh = std::min(grid_shade, (want + 7) / 8 * 8);
+        }
+        if (b == tail_from) {
+            hipLaunchKernelGGL(k_tail, dim3(g_ext), dim3(BLOCK), 0, st, ctx->scene, ps, bp, b, ctx->cam.background, ctx->stats);
+            if (prof) {
+                (void)hipEventRecord(get_event(pp, ev++), st);
+                (void)hipEventRecord(get_event(pp, ev++), st);
+            }
+            bounces++;
+            break;
         }
         launch_extend(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
         for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, q});
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
+    if (bounces_out) *bounces_out = bounces;
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
 }
@@ -1431,21 +1536,24 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         // the host runs at most two batches ahead of each pipe
         hipEvent_t done = pp.accumulated[pp.batches & 1u];
         if (pp.batches >= 2) {
+            auto w0 = std::chrono::steady_clock::now();
             HIP_TRY(ctx, hipEventSynchronize(done));
+            ctx->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             const uint32_t have = pp.host_chunks_depth[pp.batches & 1u];
             if (have) {
                 ctx->bounce_profile.assign(pp.host_chunks[pp.batches & 1u], pp.host_chunks[pp.batches & 1u] + have);
                 ctx->bounce_profile[0] = pp.host_paths[pp.batches & 1u];  // bounce 0 traces every path of the batch
             }
         }
-        if ((rc = run_batch(ctx, pp, s, k, seed))) return rc;
+        uint32_t bounces = 0;
+        if ((rc = run_batch(ctx, pp, s, k, seed, &bounces))) return rc;
         if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(pp.stream, ctx->last_accumulated, 0));
-        const size_t ev = 2 + 2 * (size_t)ctx->cam.max_depth;
+        const size_t ev = 2 + 2 * (size_t)bounces;
         if (ctx->profile) (void)hipEventRecord(get_event(pp, ev), pp.stream);
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, pp.stream, pp.ps.contrib, ctx->accum, npix, k);
         if (ctx->profile) {
             (void)hipEventRecord(get_event(pp, ev + 1), pp.stream);
-            pp.events_pending[pp.batches & 1u] = ctx->cam.max_depth;
+            pp.events_pending[pp.batches & 1u] = bounces;
         }
         {
             const uint32_t n_b = std::min<uint32_t>(ctx->cam.max_depth, BOUNCE_PROFILE_LEN);
@@ -1629,12 +1737,22 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
     out->shade_ms = ctx->shade_ms;
     out->other_ms = ctx->other_ms;
     out->render_ms = ctx->render_ms;
+    out->host_wait_ms = ctx->host_wait_ms;
     out->node_tests = ds.node_tests;
     out->tri_tests = ds.tri_tests;
     out->sphere_tests = ds.sphere_tests;
     out->quad_tests = ds.quad_tests;
     out->bad_refs = ds.bad_refs[0] + ds.bad_refs[1];
     out->device_bytes = ctx->device_bytes;
+    if (getenv("PT_DEBUG_BOUNCES") && ctx->profiled_batches) {  // per-bounce means of the event timings, for tuning
+        fprintf(stderr, "bounce: extend ms, shade ms (mean of %llu batches), rays in the last profile\n", (unsigned long long)ctx->profiled_batches);
+        for (size_t b = 0; b < ctx->bounce_extend_ms.size() && b < 12; b++)
+            fprintf(stderr, "%3zu: %8.3f %8.3f %10u\n", b, ctx->bounce_extend_ms[b] / ctx->profiled_batches, ctx->bounce_shade_ms[b] / ctx->profiled_batches,
+                    b < ctx->bounce_profile.size() ? ctx->bounce_profile[b] : 0u);
+        double te = 0, ts = 0;
+        for (size_t b = 12; b < ctx->bounce_extend_ms.size(); b++) te += ctx->bounce_extend_ms[b], ts += ctx->bounce_shade_ms[b];
+        fprintf(stderr, "12+: %8.3f %8.3f\n", te / ctx->profiled_batches, ts / ctx->profiled_batches);
+    }
     return PT_OK;
 }
 
@@ -1643,7 +1761,10 @@ int pt_stats_reset(pt_context *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = restart_epoch(ctx)) return rc;
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
-    ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = 0.0;
+    ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = ctx->host_wait_ms = 0.0;
+    ctx->bounce_extend_ms.clear();
+    ctx->bounce_shade_ms.clear();
+    ctx->profiled_batches = 0;
     return PT_OK;
 }
 

@@ -94,3 +94,26 @@ def test_per_sample_radiance_identical_across_options():
     r.set_option(PT_OPT_LEAF_BATCH, 1)
     b = r.render_samples(0, 3, seed=2)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("make,width", [(scenes.small_mixed, 32), (scenes.cornell, 48)])
+def test_accumulator_identical_wherever_the_tail_launch_takes_over(make, width):
+    # The tail launch starts once the host has the ray counts of an earlier batch of the same pipe,
+    # so render many small batches: 0 = never, 1e9 = from bounce 1, the others in between.
+    from pathtracer_amd.core import PT_OPT_MAX_PATHS, PT_OPT_PIPES, PT_OPT_TAIL_BELOW
+    src = make(width, 36)  # square images, 36 strata
+    npix = width * width
+    ref = None
+    for pipes, tail in ((1, 0), (1, 1_000_000_000), (1, 8192), (1, 600), (1, 40), (2, 600), (4, 1_000_000_000)):
+        r = _renderer(src)
+        r.set_option(PT_OPT_PIPES, pipes)
+        r.set_option(PT_OPT_MAX_PATHS, 2 * npix)
+        r.set_option(PT_OPT_TAIL_BELOW, tail)
+        r.render(0, 16, seed=5)
+        r.render(16, 31, seed=5)
+        acc, n = r.read_accum()
+        assert n == 31
+        if ref is None:
+            ref = acc
+        else:
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} tail_below={tail}"
