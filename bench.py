@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--leaf-batch", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tail-below", type=int, default=-1)
+    ap.add_argument("--rolling", type=int, default=-1, help="paths started per launch of the rolling schedule (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -76,7 +77,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -104,6 +105,8 @@ def main():
         r.set_option(PT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     if args.tail_below >= 0:
         r.set_option(PT_OPT_TAIL_BELOW, args.tail_below)
+    if args.rolling >= 0:
+        r.set_option(PT_OPT_ROLLING, args.rolling)
     total_strata = r.sqrt_spp * r.sqrt_spp
     lo, hi = stratum_ranges(total_strata, world)[rank]
     S = min(S, hi - lo)

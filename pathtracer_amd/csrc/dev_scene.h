@@ -101,6 +101,15 @@ constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material
 constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
 constexpr uint32_t CTL_WORDS = (4 + 2 * MAX_QUEUES) * CTL_STRIDE;
 
+// A launch may carry paths of several batches at once (each at a different bounce).  The slot
+// arrays are then cut into regions of region_cap slots, one batch per region, and a path's
+// batch is found from its slot.
+struct RegionParams {  // 32 B
+    uint64_t seed_mixed;
+    uint32_t stratum_first, n_strata;
+    uint32_t unused[4];
+};
+
 // Per-path state, indexed by slot = pixel * strata_in_batch + (stratum - batch_first_stratum).
 struct PathState {
     float4 *ray_o;    // origin.xyz, rng draw counter (bits)
@@ -120,6 +129,8 @@ struct PathState {
     uint32_t n_slots;
     int refill_below;          // a traversing wave with fewer busy lanes than this goes back for more rays
     int leaf_batch;            // lanes that must be waiting at a leaf before the wave runs a primitive test
+    RegionParams *regions;     // [slots / region_cap] batches the regions hold (only where batches share launches)
+    uint32_t region_cap;       // slots per region
 };
 
 }  // namespace ptd

@@ -106,15 +106,14 @@ constexpr uint32_t WALK_MAX_PASSES = 1u << 20;
 // reload(slot, o, d): the world-frame origin and direction of that ray again (INSTANCES only).
 // sink(done, slot, ray, hit): called by all 64 lanes of the wave together (so it may use
 // ballots), done == true on lanes whose ray has just been finished; ray.t_max is the hit
-// distance.  `n_chunks` chunks of the queue are in use; `cursor` counts the 64-entry pieces
+// distance.  The work is `n_pieces` pieces of 64 entries; `cursor` counts the pieces
 // handed out.  `bad_refs` is only touched in the bounds-checking build.
 template <bool INSTANCES, class Source, class Reload, class Sink>
-__device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_chunks, uint32_t *cursor, int refill_below, int leaf_batch,
+__device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces, uint32_t *cursor, int refill_below, int leaf_batch,
                                            LaneStack &st, unsigned long long *bad_refs, Source &&source, Reload &&reload, Sink &&sink) {
     const DevSet &set = sc.world;
     constexpr uint32_t PIECES = QUEUE_CHUNK / 64u;
-    const uint32_t n_pieces = n_chunks * PIECES;
-    const uint32_t claim = n_chunks >= 2u * wave_count() ? PIECES : 1u;  // pieces per atomic
+    const uint32_t claim = n_pieces >= 2u * PIECES * wave_count() ? PIECES : 1u;  // pieces per atomic
     // the cursors live in memory every XCD shares: waves that cannot get a piece do not poll them
     if ((uint64_t)wave_index() * claim >= n_pieces) return;
     uint32_t res_next = 0u, res_end = 0u;  // claimed entries not dealt yet (same on all lanes)

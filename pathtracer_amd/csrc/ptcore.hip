@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <deque>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -108,26 +109,39 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint3
     d = pixel_center - ray_center;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, BatchParams bp, DevStats *stats) {
+// ROLL: the batch goes to the region starting at slot `base`, whose parameters are recorded for
+// the kernels that meet its paths later, and no queue is written: the closest-hit kernel takes
+// the new paths by their slot numbers.
+template <bool ROLL>
+__global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, BatchParams bp, uint32_t base, DevStats *stats) {
     const uint32_t n = bp.n_slots;
-    for (uint32_t slot = blockIdx.x * BLOCK + threadIdx.x; slot < n; slot += gridDim.x * BLOCK) {
+    for (uint32_t local = blockIdx.x * BLOCK + threadIdx.x; local < n; local += gridDim.x * BLOCK) {
         uint32_t pixel, stratum;
-        slot_to_sample(bp, slot, pixel, stratum);
+        slot_to_sample(bp, local, pixel, stratum);
         Rng rng;
         rng.init(bp.seed_mixed, pixel, stratum, 0u);
         f3 o, d;
         camera_ray(cam, rng, pixel, stratum, o, d);
+        const uint32_t slot = base + local;
         ps.ray_o[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.counter));
         ps.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cam.max_depth));
         ps.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         ps.contrib[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        ps.ray_queue[0][slot] = slot;
+        if (!ROLL) ps.ray_queue[0][slot] = slot;
     }
-    const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
     if (blockIdx.x == 0) {
-        for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
+        if (!ROLL) {
+            const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
+            for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
+            if (threadIdx.x == 0) ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
+        } else if (threadIdx.x == 0) {
+            RegionParams rp{};
+            rp.seed_mixed = bp.seed_mixed;
+            rp.stratum_first = bp.stratum_first;
+            rp.n_strata = bp.n_strata;
+            ps.regions[base / ps.region_cap] = rp;
+        }
         if (threadIdx.x == 0) {
-            ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
             atomicAdd(&stats->paths_total, (unsigned long long)n);
             atomicAdd(&stats->rays_total, (unsigned long long)n);
         }
@@ -254,21 +268,31 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
 #else
 #define WALK_OCCUPANCY
 #endif
+// The work is the current ray queue followed by the `n_new` paths in slots new_base.. that a
+// k_raygen<true> has just started (no queue entries exist for those).
 template <bool INSTANCES>
-__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, uint32_t new_base,
+                                                                      uint32_t n_new, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    extend_prologue(ps, bounce, n_chunks, stats);
-    if (n_chunks == 0u) return;
+    extend_prologue(ps, bounce, n_chunks + n_new, stats);
+    const uint32_t queued = n_chunks * QUEUE_CHUNK;
+    const uint32_t n_pieces = queued / 64u + (n_new + 63u) / 64u;
+    if (n_pieces == 0u) return;
     shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     const uint32_t *queue = ps.ray_queue[parity];
     walk_world<INSTANCES>(
-        sc, n_chunks, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+        sc, n_pieces, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            slot = queue[i];
-            if (slot == QUEUE_EMPTY) return false;
+            if (i < queued) {
+                slot = queue[i];
+                if (slot == QUEUE_EMPTY) return false;
+            } else {
+                if (i - queued >= n_new) return false;
+                slot = new_base + (i - queued);
+            }
             const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
             return true;
@@ -329,9 +353,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
 
 // One path vertex: the body of Camera::ray_color after the hit (src/camera.rs:286-369), in
 // multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
-// type MT.  Returns true when the path goes on: its next ray is then in ps.ray_o / ps.ray_d.
+// type MT; `local` is its number within its batch.  Returns true when the path goes on: its
+// next ray is then in ps.ray_o / ps.ray_d.
 template <int MT>
-__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot) {
+__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local) {
     const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
     const uint32_t code = ps.hit2[slot];
     const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -346,7 +371,7 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
         ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
     } else {
         uint32_t pixel, stratum;
-        slot_to_sample(bp, slot, pixel, stratum);
+        slot_to_sample(bp, local, pixel, stratum);
         Rng rng;
         rng.init(bp.seed_mixed, pixel, stratum, __float_as_uint(ro4.w));
         const Onb surface = make_onb(s.normal);
@@ -404,7 +429,9 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
 }
 
 // shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
-template <int MT>
+// ROLL: the queue mixes batches, `bp` holds what they have in common and the rest comes from the
+// path's region.
+template <int MT, bool ROLL>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
@@ -416,7 +443,20 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
     const PieceWalk pw = piece_walk(n_chunks);
     for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
         const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        const bool alive = slot != QUEUE_EMPTY && shade_vertex<MT>(sc, ps, bp, slot);
+        bool alive = false;
+        if (slot != QUEUE_EMPTY) {
+            if constexpr (ROLL) {
+                const uint32_t region = slot / ps.region_cap;
+                const RegionParams rp = ps.regions[region];
+                BatchParams mine = bp;
+                mine.seed_mixed = rp.seed_mixed;
+                mine.stratum_first = rp.stratum_first;
+                mine.n_strata = rp.n_strata;
+                alive = shade_vertex<MT>(sc, ps, mine, slot, slot - region * ps.region_cap);
+            } else {
+                alive = shade_vertex<MT>(sc, ps, bp, slot, slot);
+            }
+        }
         if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
             survivors += (uint32_t)__popcll(__ballot(alive));
             wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
@@ -426,7 +466,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
         wave_push_close(out, ps.ray_queue[parity ^ 1u]);
         if (survivors && lane_id() == 0u) {  // rays of the next bounce
             atomicAdd(&stats->rays_total, (unsigned long long)survivors);
-            if (bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
+            if (!ROLL && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
         }
     }
 }
@@ -471,16 +511,16 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, Batch
             ps.hit2[slot] = h.code;
             bool alive = false;
             switch (sc.mats[mat].type) {
-                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN>(sc, ps, bp, slot); break;
-                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL>(sc, ps, bp, slot); break;
-                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC>(sc, ps, bp, slot); break;
-                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT>(sc, ps, bp, slot); break;
-                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY>(sc, ps, bp, slot); break;
-                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE>(sc, ps, bp, slot); break;
-                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL>(sc, ps, bp, slot); break;
-                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS>(sc, ps, bp, slot); break;
-                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT>(sc, ps, bp, slot); break;
-                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN>(sc, ps, bp, slot); break;
+                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN>(sc, ps, bp, slot, slot); break;
                 default: break;
             }
             if (!alive) break;
@@ -558,7 +598,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps,
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     walk_world<INSTANCES>(
-        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK, &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = ps.ray_queue[0][i];
             if (slot == QUEUE_EMPTY) return false;
@@ -677,8 +717,30 @@ struct pt_context {
         std::vector<hipEvent_t> events[2];
         uint32_t events_pending[2] = {0, 0};  // bounces whose events have not been read back yet
     };
+    // Rolling schedule: every launch of a pipe carries bounce 0 of the batch started with it, bounce 1
+    // of the batch before, and so on, so that no launch is thin however few paths reach the late
+    // bounces.  Batch b of the pipe lives in region b % n_regions of the slot arrays and is
+    // complete max_depth launches ("ticks") after it started.
+    static constexpr int ROLL_RING = 8;  // ticks the host may run ahead of a pipe
+    struct Due {
+        uint64_t tick;  // the tick whose shading finishes the batch
+        uint32_t region, n_strata;
+    };
+    struct Roll {
+        PathState ps{};
+        std::vector<std::pair<void *, size_t>> allocs;
+        uint32_t n_regions = 0, cap = 0;
+        uint64_t tick = 0;
+        std::deque<Due> due;
+        hipEvent_t done[ROLL_RING] = {}, accumulated[ROLL_RING] = {};
+        hipEvent_t prof[ROLL_RING][4] = {};  // before raygen, before extend, after extend, after shading
+        bool prof_pending[ROLL_RING] = {};
+    };
     static constexpr int MAX_PIPES = 8;
     Pipe pipes[MAX_PIPES];
+    Roll rolls[MAX_PIPES];
+    uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
+    uint64_t roll_paths = 1u << 22;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;
     uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
     hipEvent_t last_accumulated = nullptr;  // of the most recent batch: the next k_accumulate waits for it
@@ -757,7 +819,26 @@ static int grid_fixed(const pt_context *ctx, uint64_t upper_bound, int blocks_pe
     return (int)((blocks + 7) / 8 * 8);  // the same number of workgroups on every XCD
 }
 
+static void free_roll(pt_context *ctx, pt_context::Roll &r) {
+    free_pool(ctx, r.allocs);
+    r.n_regions = r.cap = 0;
+    r.tick = 0;
+    r.due.clear();
+    for (bool &b : r.prof_pending) b = false;
+}
 static void destroy_pipes(pt_context *ctx) {
+    for (auto &r : ctx->rolls) {
+        free_roll(ctx, r);
+        for (int i = 0; i < pt_context::ROLL_RING; i++) {
+            if (r.done[i]) (void)hipEventDestroy(r.done[i]);
+            if (r.accumulated[i]) (void)hipEventDestroy(r.accumulated[i]);
+            r.done[i] = r.accumulated[i] = nullptr;
+            for (auto &ev : r.prof[i]) {
+                if (ev) (void)hipEventDestroy(ev);
+                ev = nullptr;
+            }
+        }
+    }
     for (auto &pp : ctx->pipes) {
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
         free_pool(ctx, pp.allocs);
@@ -781,7 +862,10 @@ static void destroy_pipes(pt_context *ctx) {
     if (ctx->epoch) (void)hipEventDestroy(ctx->epoch);
     ctx->epoch = nullptr;
 }
-static void sync_pipes(pt_context *ctx) {
+static int roll_flush(pt_context *ctx);
+// Waits for everything enqueued (finish_batches: after enqueueing what the batches under way still need).
+static void sync_pipes(pt_context *ctx, bool finish_batches = true) {
+    if (finish_batches) (void)roll_flush(ctx);
     for (auto &pp : ctx->pipes)
         if (pp.stream) (void)hipStreamSynchronize(pp.stream);
 }
@@ -794,13 +878,17 @@ static void forget_bounce_profile(pt_context *ctx) {
 
 // The entry points below have C linkage through their declarations in ptcore.h.
 static void harvest_profile(pt_context *ctx, pt_context::Pipe &pp);
+static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring);
 
 // Waits for everything enqueued on the context and folds in pending event timings.
 static int sync_all(pt_context *ctx) {
-    for (auto &pp : ctx->pipes) {
+    if (int rc = roll_flush(ctx)) return rc;
+    for (int i = 0; i < pt_context::MAX_PIPES; i++) {
+        auto &pp = ctx->pipes[i];
         if (!pp.stream) continue;
         HIP_TRY(ctx, hipStreamSynchronize(pp.stream));
         harvest_profile(ctx, pp);
+        for (int ring = 0; ring < pt_context::ROLL_RING; ring++) harvest_roll(ctx, ctx->rolls[i], ring);
     }
     if (!ctx->extend_iv.empty()) {  // union of the closest-hit launches since the last call
         std::sort(ctx->extend_iv.begin(), ctx->extend_iv.end());
@@ -871,6 +959,11 @@ int pt_create(int device, pt_context **out) {
         if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated[k], hipEventDisableTiming);
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc((void **)&ctx->pipes[i].host_chunks[k], BOUNCE_PROFILE_LEN * sizeof(uint32_t), hipHostMallocDefault);
+        for (int k = 0; k < pt_context::ROLL_RING && e == hipSuccess; k++) {
+            e = hipEventCreateWithFlags(&ctx->rolls[i].done[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->rolls[i].accumulated[k], hipEventDisableTiming);
+            for (int j = 0; j < 4 && e == hipSuccess; j++) e = hipEventCreate(&ctx->rolls[i].prof[k][j]);
+        }
     }
     void *p = nullptr;
     if (e != hipSuccess || (e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
@@ -887,7 +980,7 @@ int pt_create(int device, pt_context **out) {
 void pt_destroy(pt_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    sync_pipes(ctx);
+    sync_pipes(ctx, false);
     free_pool(ctx, ctx->scene_allocs);
     if (ctx->accum) (void)hipFree(ctx->accum);
     if (ctx->rgb8) (void)hipFree(ctx->rgb8);
@@ -900,6 +993,8 @@ const char *pt_last_error(const pt_context *ctx) { return ctx ? ctx->err.c_str()
 
 int pt_set_option(pt_context *ctx, int key, double value) {
     if (!ctx) return PT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    sync_pipes(ctx);  // batches under way finish under the settings they started with
     switch (key) {
         case PT_OPT_BSDF_SAMPLE_PROBABILITY:
             if (!(value >= 0.0 && value <= 1.0)) return fail(ctx, PT_ERR_INVALID, "bsdf sample probability must be in [0,1]");
@@ -935,6 +1030,11 @@ int pt_set_option(pt_context *ctx, int key, double value) {
                 free_pool(ctx, pp.allocs);
                 pp.capacity = 0;
             }
+            for (auto &r : ctx->rolls) free_roll(ctx, r);
+            return PT_OK;
+        case PT_OPT_ROLLING:
+            if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "paths per launch out of range");
+            ctx->roll_paths = (uint64_t)value;
             return PT_OK;
         case PT_OPT_TAIL_BELOW:
             if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "tail threshold out of range");
@@ -1262,6 +1362,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         free_pool(ctx, pp.allocs);
         pp.capacity = 0;
     }
+    for (auto &r : ctx->rolls) free_roll(ctx, r);
     return PT_OK;
 }
 
@@ -1354,7 +1455,8 @@ static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
 }
 
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
-static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce) {
+// new_base, n_new: paths a k_raygen<true> has just started (only with the ray-drawing kernel).
+static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, uint32_t new_base = 0, uint32_t n_new = 0) {
     const dim3 g(grid), b(BLOCK);
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
@@ -1363,8 +1465,8 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
     if (ctx->counters) {
         if (insts) { EXT(true, false); EXI(true); } else EXT(true, true);
     } else if (ctx->use_wide()) {
-        if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats);
-        else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats);
+        if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, bounce, bg, new_base, n_new, ctx->stats);
+        else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, bounce, bg, new_base, n_new, ctx->stats);
     } else {
         if (insts) { EXT(false, false); EXI(false); } else EXT(false, true);
     }
@@ -1379,10 +1481,12 @@ struct ShadeLaunch {
     int grid;
     const BatchParams *bp;
     uint32_t bounce, q;
+    bool roll = false;
 };
 template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
-    hipLaunchKernelGGL(k_shade<MT>, dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats);
+    if (l.roll) hipLaunchKernelGGL((k_shade<MT, true>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats);
+    else hipLaunchKernelGGL((k_shade<MT, false>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats);
 }
 static void launch_shade_type(int type, const ShadeLaunch &l) {
     switch (type) {
@@ -1459,7 +1563,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     size_t ev = 0;
     const bool prof = ctx->profile;
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(ctx, n_slots)), dim3(BLOCK), 0, st, ctx->cam, ps, bp, ctx->stats);
+    hipLaunchKernelGGL(k_raygen<false>, dim3(grid_for(ctx, n_slots)), dim3(BLOCK), 0, st, ctx->cam, ps, bp, 0u, ctx->stats);
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     const int grid = grid_fixed(ctx, n_slots), grid_shade = grid_fixed(ctx, n_slots, ctx->shade_blocks_per_cu);
     const uint32_t depth = ctx->cam.max_depth;
@@ -1507,6 +1611,149 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     return PT_OK;
 }
 
+// ---------------------------------------------------------------- rolling schedule
+// Slot arrays of n_regions * cap paths and queues for the case that all of them are alive.
+static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &r, uint32_t n_regions, uint32_t cap) {
+    if (r.n_regions == n_regions && r.cap == cap) return PT_OK;
+    (void)hipStreamSynchronize(pp.stream);  // the caller has finished the batches under way
+    free_roll(ctx, r);
+    const uint64_t total = (uint64_t)n_regions * cap;
+    PathState ps{};
+    int rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_o, total))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_d, total))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.beta, total))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.hit, total))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.hit2, total))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.contrib, total))) return rc;
+    const uint64_t max_waves = (uint64_t)ctx->n_cu * std::max({ctx->blocks_per_cu, ctx->shade_blocks_per_cu, 8}) * (BLOCK / 64);
+    const uint64_t max_chunks = total / (QUEUE_CHUNK - 63u) + max_waves + 8u;
+    ps.max_chunks = (uint32_t)max_chunks;
+    ps.n_queues = ctx->n_queues;
+    for (int k = 0; k < 2; k++)
+        if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_queue[k], max_chunks * QUEUE_CHUNK))) return rc;
+    for (uint32_t q = 0; q < ctx->n_queues; q++)
+        if ((rc = dev_alloc(ctx, r.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.regions, (size_t)n_regions))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), pp.stream));
+    HIP_TRY(ctx, hipMemsetAsync(ps.regions, 0, n_regions * sizeof(RegionParams), pp.stream));
+    ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
+    const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
+    if ((rc = dev_alloc(ctx, r.allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
+    ps.n_slots = (uint32_t)total;
+    ps.region_cap = cap;
+    r.ps = ps;
+    r.n_regions = n_regions;
+    r.cap = cap;
+    return PT_OK;
+}
+
+// Bytes ensure_roll allocates per pipe, near enough.
+static uint64_t roll_bytes(const pt_context *ctx, uint64_t n_regions, uint64_t cap) {
+    const uint64_t total = n_regions * cap;
+    return total * 84u + (total + total / 3u) * 4u * (2u + ctx->n_queues);
+}
+
+static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
+    if (!r.prof_pending[ring]) return;
+    r.prof_pending[ring] = false;
+    if (hipEventSynchronize(r.prof[ring][3]) != hipSuccess) return;
+    float ms = 0, since = 0;
+    if (hipEventElapsedTime(&ms, r.prof[ring][0], r.prof[ring][1]) == hipSuccess) ctx->other_ms += ms;
+    if (hipEventElapsedTime(&ms, r.prof[ring][1], r.prof[ring][2]) == hipSuccess) {
+        ctx->extend_ms += ms;
+        if (hipEventElapsedTime(&since, ctx->epoch, r.prof[ring][1]) == hipSuccess) ctx->extend_iv.push_back({since, since + ms});
+    }
+    if (hipEventElapsedTime(&ms, r.prof[ring][2], r.prof[ring][3]) == hipSuccess) ctx->shade_ms += ms;
+    ctx->profiled_batches++;
+}
+
+// One tick of the next pipe in turn.  `nb` (may be null): the batch to start with it; bp->n_slots <= cap.
+static int roll_step(pt_context *ctx, const BatchParams *nb) {
+    const int p = (int)(ctx->roll_seq % (uint64_t)ctx->n_pipes);
+    pt_context::Pipe &pp = ctx->pipes[p];
+    pt_context::Roll &r = ctx->rolls[p];
+    const int ring = (int)(r.tick % pt_context::ROLL_RING);
+    if (r.tick >= (uint64_t)pt_context::ROLL_RING) {
+        auto w0 = std::chrono::steady_clock::now();
+        HIP_TRY(ctx, hipEventSynchronize(r.done[ring]));
+        ctx->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        harvest_roll(ctx, r, ring);
+    }
+    hipStream_t st = pp.stream;
+    r.ps.refill_below = ctx->refill_below;
+    r.ps.leaf_batch = ctx->leaf_batch;
+    const PathState ps = r.ps;
+    const uint32_t depth = ctx->cam.max_depth;
+    const uint32_t region = (uint32_t)(r.tick % r.n_regions), base = region * r.cap;
+    const uint32_t parity = (uint32_t)(r.tick & 1u);
+    const bool prof = ctx->profile;
+    if (prof) (void)hipEventRecord(r.prof[ring][0], st);
+    uint32_t n_new = 0;
+    if (nb) {
+        n_new = nb->n_slots;
+        hipLaunchKernelGGL(k_raygen<true>, dim3(grid_for(ctx, n_new)), dim3(BLOCK), 0, st, ctx->cam, ps, *nb, base, ctx->stats);
+        r.due.push_back({r.tick + depth - 1u, region, nb->n_strata});
+    }
+    if (prof) (void)hipEventRecord(r.prof[ring][1], st);
+    const uint64_t bound = (uint64_t)r.n_regions * r.cap;
+    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, base, n_new);
+    if (prof) (void)hipEventRecord(r.prof[ring][2], st);
+    BatchParams common{};
+    common.npix = ctx->cam.width * ctx->cam.height;
+    common.bsdf_prob = ctx->bsdf_prob;
+    const int grid_shade = grid_fixed(ctx, bound, ctx->shade_blocks_per_cu);
+    for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, true});
+    if (prof) {
+        (void)hipEventRecord(r.prof[ring][3], st);
+        r.prof_pending[ring] = true;
+    }
+    if (!r.due.empty() && r.due.front().tick == r.tick) {
+        // in stratum order over all pipes: ticks go round the pipes, so batches fall due in the order they started
+        const pt_context::Due d = r.due.front();
+        r.due.pop_front();
+        if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_accumulated, 0));
+        hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, common.npix)), dim3(BLOCK), 0, st, ps.contrib + (size_t)d.region * r.cap, ctx->accum, common.npix,
+                           d.n_strata);
+        HIP_TRY(ctx, hipEventRecord(r.accumulated[ring], st));
+        ctx->last_accumulated = r.accumulated[ring];
+    }
+    HIP_TRY(ctx, hipEventRecord(r.done[ring], st));
+    r.tick++;
+    ctx->roll_seq++;
+    return PT_OK;
+}
+
+// Enqueues the ticks that the batches under way still need.
+static int roll_flush(pt_context *ctx) {
+    for (;;) {
+        bool any = false;
+        for (int p = 0; p < ctx->n_pipes; p++) any = any || !ctx->rolls[p].due.empty();
+        if (!any) return PT_OK;
+        if (int rc = roll_step(ctx, nullptr)) return rc;
+    }
+}
+
+// Strata per tick of the rolling schedule for the current camera, 0 when the batch-at-a-time schedule is
+// to be used (switched off, counting or reference-order traversal, or the regions would not fit).
+static uint32_t roll_strata(pt_context *ctx) {
+    const uint32_t depth = ctx->cam.max_depth;
+    if (ctx->roll_paths == 0 || ctx->counters || !ctx->use_wide() || depth == 0 || depth > 256) return 0;
+    const uint64_t npix = (uint64_t)ctx->cam.width * ctx->cam.height;
+    uint64_t k = std::max<uint64_t>(1, std::min(ctx->roll_paths, ctx->max_paths) / npix);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+    uint64_t have = free_b;
+    for (int p = 0; p < ctx->n_pipes; p++)
+        for (const auto &a : ctx->rolls[p].allocs) have += a.second;  // what is there would be replaced
+    const uint64_t budget = have / 2 / (uint64_t)ctx->n_pipes;
+    while (k > 1 && roll_bytes(ctx, depth, npix * k) > budget) k--;
+    if (roll_bytes(ctx, depth, npix * k) > budget || (uint64_t)depth * npix * k > (1ull << 31)) return 0;
+    return (uint32_t)k;
+}
+
 static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PT_ERR_STATE, "upload a scene and set a camera before rendering");
@@ -1525,6 +1772,28 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     // the share of its thin late bounces; consecutive calls keep the other pipes busy.
     const uint32_t total = stratum_end - stratum_begin;
     if (total == 0) return PT_OK;
+    if (const uint32_t k_tick = roll_strata(ctx)) {
+        const uint32_t depth = ctx->cam.max_depth, cap_slots = npix * k_tick;
+        bool fits = true;
+        for (int p = 0; p < ctx->n_pipes; p++) fits = fits && ctx->rolls[p].n_regions == depth && ctx->rolls[p].cap == cap_slots;
+        if (!fits) {
+            sync_pipes(ctx);
+            for (int p = 0; p < ctx->n_pipes; p++)
+                if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], depth, cap_slots))) return rc;
+        }
+        const uint32_t n_batches = (total + k_tick - 1) / k_tick, per_batch = (total + n_batches - 1) / n_batches;
+        for (uint32_t s = stratum_begin; s < stratum_end;) {
+            const uint32_t k = std::min(per_batch, stratum_end - s);
+            BatchParams bp{mix64_host(seed), s, k, npix, npix * k, ctx->bsdf_prob};
+            if ((rc = roll_step(ctx, &bp))) return rc;
+            ctx->n_samples += k;
+            s += k;
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->render_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return PT_OK;
+    }
+    if ((rc = roll_flush(ctx))) return rc;  // what the rolling schedule has under way is accumulated first
     const uint32_t cap = (uint32_t)std::max<uint64_t>(1, ctx->max_paths / npix);
     const uint32_t n_batches = (total + cap - 1) / cap;
     const uint32_t per_batch = (total + n_batches - 1) / n_batches;

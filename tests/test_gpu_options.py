@@ -117,3 +117,39 @@ def test_accumulator_identical_wherever_the_tail_launch_takes_over(make, width):
             ref = acc
         else:
             assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} tail_below={tail}"
+
+
+@pytest.mark.parametrize("make,width", [(scenes.small_mixed, 32), (scenes.cornell, 48)])
+def test_accumulator_identical_with_batches_sharing_launches(make, width):
+    # PT_OPT_ROLLING = paths started per launch; 0 = every batch has its launches to itself
+    from pathtracer_amd.core import PT_OPT_PIPES, PT_OPT_ROLLING
+    src = make(width, 36)
+    npix = width * width
+    ref = None
+    for pipes, rolling in ((1, 0), (1, npix), (1, 3 * npix), (2, 2 * npix), (3, npix), (4, 1 << 22)):
+        r = _renderer(src)
+        r.set_option(PT_OPT_PIPES, pipes)
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.render(0, 16, seed=5)
+        r.render(16, 17, seed=5)
+        r.render(17, 31, seed=5)
+        acc, n = r.read_accum()
+        assert n == 31
+        if ref is None:
+            ref = acc
+        else:
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} rolling={rolling}"
+
+
+def test_rolling_schedule_survives_setting_changes_between_calls():
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_ROLLING
+    src = scenes.small_mixed(32, 36)
+    accs = []
+    for rolling in (0, 2 * 32 * 32):
+        r = _renderer(src)
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.render(0, 9, seed=1)
+        r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, 0.5)  # applies to the batches started after it
+        r.render(9, 20, seed=2)
+        accs.append(r.read_accum()[0])
+    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
