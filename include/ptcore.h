@@ -162,13 +162,14 @@ enum {
     PT_OPT_PROFILE = 2,                 /* 1: bracket kernels with HIP events, fill *_ms */
     PT_OPT_COUNTERS = 3,                /* 1: count AABB / primitive tests (implies the reference-order traversal) */
     PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes */
-    PT_OPT_PIPES = 5,                   /* batches of one render call in flight at once, each on its own stream; 1..8, default 4 */
+    PT_OPT_PIPES = 5,                   /* streams the batches are spread over; 1..8, default 2 with the rolling schedule
+                                           (PT_OPT_ROLLING) and 4 without */
     PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 24 */
     PT_OPT_LEAF_BATCH = 7,              /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 8 */
     PT_OPT_BLOCKS_PER_CU = 8,           /* resident workgroups per CU of the traversal kernels; 1..5, default 4 */
     PT_OPT_ROLLING = 10,                /* paths started per launch of the rolling schedule, in which every launch carries
                                            bounce 0 of a new batch together with the later bounces of the batches before it;
-                                           0 = one batch at a time per pipe; default 4194304 */
+                                           0 = one batch at a time per pipe; default 8388608 */
     PT_OPT_TAIL_BELOW = 9               /* once a bounce is expected to carry fewer rays than this, one launch finishes the
                                            batch instead of per-bounce launches; 0 = never (default:
                                            measured no faster on the benchmark scenes) */

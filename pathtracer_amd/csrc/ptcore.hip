@@ -740,8 +740,9 @@ struct pt_context {
     Pipe pipes[MAX_PIPES];
     Roll rolls[MAX_PIPES];
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
-    uint64_t roll_paths = 1u << 22;  // paths started per tick; 0 = one batch at a time per pipe
-    int n_pipes = 4;
+    uint64_t roll_paths = 1u << 23;  // paths started per tick; 0 = one batch at a time per pipe
+    int n_pipes = 4;       // batch-at-a-time schedule
+    int n_roll_pipes = 2;  // rolling schedule: its launches are all large, two pipes cover each other's ramps
     uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
     hipEvent_t last_accumulated = nullptr;  // of the most recent batch: the next k_accumulate waits for it
     // Rays per bounce of the most recent finished batch ([0] = its paths): launches of later batches are
@@ -1016,7 +1017,7 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_PIPES:
             if (!(value >= 1.0 && value <= (double)pt_context::MAX_PIPES)) return fail(ctx, PT_ERR_INVALID, "pipes must be in [1,%d]", pt_context::MAX_PIPES);
             sync_pipes(ctx);
-            ctx->n_pipes = (int)value;
+            ctx->n_pipes = ctx->n_roll_pipes = (int)value;
             return PT_OK;
         case PT_OPT_REFILL_BELOW:
             if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "refill threshold must be in [1,64]");
@@ -1672,7 +1673,7 @@ static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
 
 // One tick of the next pipe in turn.  `nb` (may be null): the batch to start with it; bp->n_slots <= cap.
 static int roll_step(pt_context *ctx, const BatchParams *nb) {
-    const int p = (int)(ctx->roll_seq % (uint64_t)ctx->n_pipes);
+    const int p = (int)(ctx->roll_seq % (uint64_t)ctx->n_roll_pipes);
     pt_context::Pipe &pp = ctx->pipes[p];
     pt_context::Roll &r = ctx->rolls[p];
     const int ring = (int)(r.tick % pt_context::ROLL_RING);
@@ -1730,7 +1731,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb) {
 static int roll_flush(pt_context *ctx) {
     for (;;) {
         bool any = false;
-        for (int p = 0; p < ctx->n_pipes; p++) any = any || !ctx->rolls[p].due.empty();
+        for (int p = 0; p < ctx->n_roll_pipes; p++) any = any || !ctx->rolls[p].due.empty();
         if (!any) return PT_OK;
         if (int rc = roll_step(ctx, nullptr)) return rc;
     }
@@ -1746,9 +1747,9 @@ static uint32_t roll_strata(pt_context *ctx) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
     uint64_t have = free_b;
-    for (int p = 0; p < ctx->n_pipes; p++)
+    for (int p = 0; p < ctx->n_roll_pipes; p++)
         for (const auto &a : ctx->rolls[p].allocs) have += a.second;  // what is there would be replaced
-    const uint64_t budget = have / 2 / (uint64_t)ctx->n_pipes;
+    const uint64_t budget = have / 2 / (uint64_t)ctx->n_roll_pipes;
     while (k > 1 && roll_bytes(ctx, depth, npix * k) > budget) k--;
     if (roll_bytes(ctx, depth, npix * k) > budget || (uint64_t)depth * npix * k > (1ull << 31)) return 0;
     return (uint32_t)k;
@@ -1775,10 +1776,10 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     if (const uint32_t k_tick = roll_strata(ctx)) {
         const uint32_t depth = ctx->cam.max_depth, cap_slots = npix * k_tick;
         bool fits = true;
-        for (int p = 0; p < ctx->n_pipes; p++) fits = fits && ctx->rolls[p].n_regions == depth && ctx->rolls[p].cap == cap_slots;
+        for (int p = 0; p < ctx->n_roll_pipes; p++) fits = fits && ctx->rolls[p].n_regions == depth && ctx->rolls[p].cap == cap_slots;
         if (!fits) {
             sync_pipes(ctx);
-            for (int p = 0; p < ctx->n_pipes; p++)
+            for (int p = 0; p < ctx->n_roll_pipes; p++)
                 if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], depth, cap_slots))) return rc;
         }
         const uint32_t n_batches = (total + k_tick - 1) / k_tick, per_batch = (total + n_batches - 1) / n_batches;

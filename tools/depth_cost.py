@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from pathtracer_amd import scenes
-from pathtracer_amd.core import HostScene, Renderer, PT_OPT_PROFILE, PT_OPT_TAIL_BELOW
+from pathtracer_amd.core import HostScene, Renderer, PT_OPT_PROFILE, PT_OPT_ROLLING, PT_OPT_TAIL_BELOW
 
 import sys as _s
 for depth in ([int(a) for a in _s.argv[1:]] or (4, 8, 16, 50)):
@@ -11,6 +11,8 @@ for depth in ([int(a) for a in _s.argv[1:]] or (4, 8, 16, 50)):
     r = Renderer(HostScene(src))
     if os.environ.get("TAIL_BELOW"):
         r.set_option(PT_OPT_TAIL_BELOW, int(os.environ["TAIL_BELOW"]))
+    if os.environ.get("ROLLING"):
+        r.set_option(PT_OPT_ROLLING, int(os.environ["ROLLING"]))
     if os.environ.get("PT_DEBUG_BOUNCES"):
         r.set_option(PT_OPT_PROFILE, 1)
     r.render(0, 128, seed=1)
