@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--leaf-batch", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tail-below", type=int, default=-1)
-    ap.add_argument("--rolling", type=int, default=-1, help="paths started per launch of the rolling schedule (0: off)")
+    ap.add_argument("--rolling", type=int, default=12_000_000,
+                    help="paths started per launch of the rolling schedule (0: one batch at a time per pipe; -1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -193,7 +194,9 @@ def main():
                                    f"{host.desc.n_spheres} spheres, {host.desc.n_quads} quads, {host.desc.n_instances} instances"
                                    + (" (procedural stand-in for mitsuba_smooth.obj, Disney + Lambertian + emitter)" if args.scene == "knob" else "")
                                    + f", {S} full-frame strata per step per GPU",
-                       "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce"},
+                       "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce",
+                       "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
+                                    "library default" if args.rolling < 0 else "one batch at a time per pipe")},
             "roofline": {"bound": "hbm", "kernel": "k_extend_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
