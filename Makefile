@@ -9,7 +9,7 @@ ARCH ?= gfx950
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -std=c++17 -Wall
 HOSTFLAGS = -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -std=c++17 -Wall -Wextra
 
-CORE_SRC = pathtracer_amd/csrc/ptcore.hip
+CORE_SRC = pathtracer_amd/csrc/ptcore.hip pathtracer_amd/csrc/bvh_build.hip
 CORE_DEP = $(wildcard pathtracer_amd/csrc/*.h) include/ptcore.h include/ptscene_src.h
 HOST_DEP = pathtracer_amd/host/pthost.hpp include/pthost.h include/ptcore.h include/ptscene_src.h
 

@@ -170,6 +170,11 @@ enum {
     PT_OPT_ROLLING = 10,                /* paths started per launch of the rolling schedule, in which every launch carries
                                            bounce 0 of a new batch together with the later bounces of the batches before it;
                                            0 = one batch at a time per pipe; default 8388608 */
+    PT_OPT_DEVICE_BVH = 11,             /* a triangle buffer that is uploaded without nodes and has at least this many
+                                           triangles gets its BVH built on the device during pt_upload_scene (a different
+                                           tree from the host builder's: same closest distances, the winner among exact
+                                           ties may differ; triangles are reordered, see pt_read_triangle_order);
+                                           0 = never (default): such buffers are searched in order */
     PT_OPT_TAIL_BELOW = 9               /* once a bounce is expected to carry fewer rays than this, one launch finishes the
                                            batch instead of per-bounce launches; 0 = never (default:
                                            measured no faster on the benchmark scenes) */
@@ -218,6 +223,10 @@ int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples);
 /* (sum / n_samples).to_rgb() per pixel (src/camera.rs:221-226, src/types/color.rs:68-78). */
 int pt_read_rgb8(pt_context *ctx, uint8_t *rgb);
 int pt_reset_accum(pt_context *ctx);
+/* order[i] = index in the uploaded triangle arrays of the triangle that pt_hit::prim_id == i names
+ * (the identity unless PT_OPT_DEVICE_BVH reordered a buffer); n must be the scene's triangle count.
+ * No counterpart in the reference, whose builder permutes its Vec in place (src/bvh.rs:295-311). */
+int pt_read_triangle_order(pt_context *ctx, uint32_t *order, uint32_t n);
 /* Device-to-device copies of the accumulator, for a collective on device memory
  * (W*H*3 f32).  `stream_sync` semantics: both block until the copy is complete. */
 int pt_copy_accum_to_device(pt_context *ctx, void *dst_device);

@@ -24,6 +24,9 @@ typedef struct pth_scene pth_scene;
  * constants from the description.  Returns NULL and fills err on failure — including the
  * case where the reference would panic (BVH deeper than 63 levels, src/bvh.rs:484-486). */
 pth_scene *pth_scene_build(const pts_scene *scene, const pts_camera *camera, char *err, size_t errlen);
+/* The same, leaving triangle buffers of at least skip_tri_bvh_from triangles (0: none) without a BVH, in
+ * insertion order, for a device library that builds its own (PT_OPT_DEVICE_BVH of ptcore.h). */
+pth_scene *pth_scene_build_opts(const pts_scene *scene, const pts_camera *camera, uint32_t skip_tri_bvh_from, char *err, size_t errlen);
 void pth_scene_free(pth_scene *s);
 
 /* Flat views; valid until pth_scene_free. */

@@ -21,7 +21,7 @@ _host: Optional[C.CDLL] = None
 
 PT_NODE_LEAF = 0x80000000
 (PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS, PT_OPT_TRAVERSAL, PT_OPT_PIPES,
- PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_BLOCKS_PER_CU, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING) = range(11)
+ PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_BLOCKS_PER_CU, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_DEVICE_BVH) = range(12)
 
 
 class PtError(RuntimeError):
@@ -81,13 +81,14 @@ class pt_stats(C.Structure):
                 ("bad_refs", C.c_uint64)]
 
 
+PT_PRIM_TRI, PT_PRIM_SPHERE, PT_PRIM_QUAD = 0, 1, 2  # pt_hit::prim_type
 HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
 
 # every symbol include/ptcore.h and include/pthost.h declare
 CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
-                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum",
+                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
                 "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
-HOST_SYMBOLS = ["pth_scene_build", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
+HOST_SYMBOLS = ["pth_scene_build", "pth_scene_build_opts", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
                 "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles"]
 
 
@@ -112,6 +113,7 @@ def core_lib() -> C.CDLL:
         L.pt_trace_first_hit.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_read_accum.argtypes = [vp, vp, vp]
         L.pt_read_rgb8.argtypes = [vp, vp]
+        L.pt_read_triangle_order.argtypes = [vp, vp, C.c_uint32]
         L.pt_reset_accum.argtypes = [vp]
         L.pt_copy_accum_to_device.argtypes = [vp, vp]
         L.pt_set_accum_from_device.argtypes = [vp, vp, C.c_uint32]
@@ -129,6 +131,8 @@ def host_lib() -> C.CDLL:
         vp = C.c_void_p
         L.pth_scene_build.argtypes = [vp, vp, C.c_char_p, C.c_size_t]
         L.pth_scene_build.restype = vp
+        L.pth_scene_build_opts.argtypes = [vp, vp, C.c_uint32, C.c_char_p, C.c_size_t]
+        L.pth_scene_build_opts.restype = vp
         L.pth_scene_free.argtypes = [vp]
         L.pth_scene_free.restype = None
         L.pth_scene_desc.argtypes = [vp]
@@ -192,11 +196,14 @@ NODE_DTYPE = np.dtype([("bmin", np.float32, 3), ("bmax", np.float32, 3), ("a", n
 class HostScene:
     """A scene after the host layer built it: primitives in post-build order, flat BVHs, camera constants."""
 
-    def __init__(self, src: SceneSource):
+    def __init__(self, src: SceneSource, device_bvh_from: int = 0):
+        """device_bvh_from: triangle buffers of at least this many triangles are left without a BVH here and get
+        one built on the device when a Renderer uploads the scene (0: the host builds every BVH)."""
         self.src = src
+        self.device_bvh_from = int(device_bvh_from)
         sc, cam = src.to_c()
         err = C.create_string_buffer(512)
-        self.h = host_lib().pth_scene_build(C.byref(sc), C.byref(cam), err, 512)
+        self.h = host_lib().pth_scene_build_opts(C.byref(sc), C.byref(cam), self.device_bvh_from, err, 512)
         if not self.h:
             raise PtError("pth_scene_build: " + err.value.decode())
         self.desc = host_lib().pth_scene_desc(self.h).contents
@@ -257,6 +264,8 @@ class Renderer:
         if rc:
             raise PtError("pt_create: " + self.L.pt_last_error(None).decode())
         self.ctx = h
+        if getattr(scene, "device_bvh_from", 0):
+            self.set_option(PT_OPT_DEVICE_BVH, scene.device_bvh_from)
         self._check(self.L.pt_upload_scene(self.ctx, C.byref(scene.desc)), "pt_upload_scene")
         self._check(self.L.pt_set_camera(self.ctx, C.byref(scene.camera)), "pt_set_camera")
         self.width, self.height, self.sqrt_spp = scene.width, scene.height, scene.sqrt_spp
@@ -283,6 +292,12 @@ class Renderer:
 
     def sync(self):
         self._check(self.L.pt_sync(self.ctx), "pt_sync")
+
+    def triangle_order(self) -> np.ndarray:
+        """order[i] = index in the uploaded triangle arrays of the triangle that hit records call i."""
+        out = np.zeros(self.scene.desc.n_tris, np.uint32)
+        self._check(self.L.pt_read_triangle_order(self.ctx, out.ctypes.data_as(C.c_void_p), out.size), "pt_read_triangle_order")
+        return out
 
     def render_samples(self, stratum_begin: int, stratum_end: int, seed: int = 0) -> np.ndarray:
         out = np.zeros((stratum_end - stratum_begin, self.npix, 3), np.float32)

@@ -24,6 +24,8 @@ struct DevBuffer {
     uint32_t wide_first;              // first 64-byte node of this buffer in `wide`
     uint32_t root_ref;                // reference to the root (a wide-node index or a leaf reference)
     float rmin[3], rmax[3];           // the root's own box
+    uint32_t tree;                    // 0: no BVH, primitives are tested in order; 1: `nodes` and `wide`;
+                                      // 2: `wide` only (built on the device, bvh_build.h)
 };
 // Child references inside wide nodes: an index into the buffer's wide nodes, or
 // WIDE_LEAF | count << 24 | offset (count <= 127, offset < 2^24) for a leaf.
@@ -57,6 +59,7 @@ struct DevScene {
     const pts_texture *textures;
     const pts_image *images;
     const uint8_t *texels;
+    const uint32_t *tri_order;  // [n_tris] position at upload of the triangle now at each position
     DevSet world;   // sets[0]
     DevSet lights;  // sets[1]
     uint32_t n_materials;

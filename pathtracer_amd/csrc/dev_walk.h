@@ -53,7 +53,7 @@ constexpr uint32_t PHASE_INSTS = 3u, PHASE_CHILD = 4u, PHASE_DONE = 7u, PHASE_ID
 // First node of a buffer for ray r: the buffer's own early-outs and the root's box.
 __device__ __forceinline__ uint32_t walk_begin(const DevBuffer &buf, const TravRay &r) {
     if (buf.prim_count == 0) return REF_NONE;
-    if (buf.node_count == 0) return REF_LINEAR;
+    if (buf.tree == 0u) return REF_LINEAR;
     float e;
     if (!slab_test_entry(buf.rmin[0], buf.rmin[1], buf.rmin[2], buf.rmax[0], buf.rmax[1], buf.rmax[2], r, e)) return REF_NONE;
     return buf.root_ref;

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <deque>
 #include <chrono>
 #include <cmath>
@@ -24,6 +25,7 @@
 #include <string>
 #include <vector>
 
+#include "bvh_build.h"
 #include "dev_shade.h"
 #include "dev_walk.h"
 
@@ -683,6 +685,7 @@ struct pt_context {
     int blocks_per_cu = 4;
 #endif
     int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
+    uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
     int tail_below = 0;  // rays under which the rest of a batch goes to one launch (0: never)
 
     // scene
@@ -1033,6 +1036,10 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             }
             for (auto &r : ctx->rolls) free_roll(ctx, r);
             return PT_OK;
+        case PT_OPT_DEVICE_BVH:
+            if (!(value >= 0.0 && value <= 4.0e9)) return fail(ctx, PT_ERR_INVALID, "triangle count out of range");
+            ctx->device_bvh_min = (uint32_t)value;
+            return PT_OK;
         case PT_OPT_ROLLING:
             if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "paths per launch out of range");
             ctx->roll_paths = (uint64_t)value;
@@ -1260,15 +1267,18 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     std::vector<DevSet> sets(s->n_sets);
     std::vector<float4> wide;
     bool wide_ok = true;
-    std::vector<uint32_t> set_depth(s->n_sets, 0);  // deepest BVH among the non-instance buffers of a set
-    uint32_t world_inst_depth = 0;
-    auto cvt = [&](const pt_buffer_desc &b, uint32_t &depth) {
+    // depth of the BVH of each buffer: [set][triangles, spheres, quads, instances]
+    std::vector<std::array<uint32_t, 4>> depth_of(s->n_sets, std::array<uint32_t, 4>{0, 0, 0, 0});
+    struct DeviceBuild {
+        uint32_t set, n, prim_first, wide_first;
+    };
+    std::vector<DeviceBuild> builds;
+    auto cvt = [&](const pt_buffer_desc &b, uint32_t k, int type) {
         DevBuffer d{};
         d.prim_first = b.prim_first;
         d.prim_count = b.prim_count;
         d.node_first = b.node_first;
         d.node_count = b.node_count;
-        depth = 0;
         if (b.node_count) {
             WideBuild wb{};
             if (!build_wide(s->nodes + b.node_first, b.node_count, wide, wb)) wide_ok = false;
@@ -1276,23 +1286,20 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
             d.root_ref = wb.root_ref;
             std::memcpy(d.rmin, wb.rmin, 12);
             std::memcpy(d.rmax, wb.rmax, 12);
-            depth = wb.depth;
+            d.tree = 1;
+            depth_of[k][type] = wb.depth;
+        } else if (type == 0 && ctx->device_bvh_min && b.prim_count >= ctx->device_bvh_min) {
+            d.wide_first = (uint32_t)(wide.size() / 4);
+            wide.resize(wide.size() + 4 * (size_t)(b.prim_count - 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            d.tree = 2;  // root and box follow from the build below
+            builds.push_back({k, b.prim_count, b.prim_first, d.wide_first});
         }
         return d;
     };
-    for (uint32_t k = 0; k < s->n_sets; k++) {
-        uint32_t dt, ds, dq, di;
-        sets[k] = DevSet{cvt(s->sets[k].tris, dt), cvt(s->sets[k].spheres, ds), cvt(s->sets[k].quads, dq), cvt(s->sets[k].instances, di)};
-        set_depth[k] = std::max(dt, std::max(ds, dq));
-        if (k == 0) world_inst_depth = di;
-    }
-    // stack entries a ray can hold at once: one per level of the BVH it is in, plus, inside
-    // an instance, those of the instance BVH above it
-    uint32_t child_depth = 0;
-    for (uint32_t k = 2; k < s->n_sets; k++) child_depth = std::max(child_depth, set_depth[k]);
-    // + the newest entry kept in registers, + the two records an instance descent leaves on the stack
-    ctx->stack_need = std::max(set_depth[0], world_inst_depth + child_depth) + 4u;
-    ctx->wide_ok = wide_ok;
+    for (uint32_t k = 0; k < s->n_sets; k++)
+        sets[k] = DevSet{cvt(s->sets[k].tris, k, 0), cvt(s->sets[k].spheres, k, 1), cvt(s->sets[k].quads, k, 2), cvt(s->sets[k].instances, k, 3)};
+    for (const DeviceBuild &b : builds)
+        if (b.n > (1u << 24)) return fail(ctx, PT_ERR_UNSUPPORTED, "set %u: more than 2^24 triangles in one buffer", b.set);
     bool boxes_finite = true;
     for (uint32_t i = 0; i < s->n_nodes && boxes_finite; i++)
         for (int k = 0; k < 3; k++) boxes_finite = boxes_finite && std::isfinite(s->nodes[i].bmin[k]) && std::isfinite(s->nodes[i].bmax[k]);
@@ -1323,6 +1330,37 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     d.tri_mat = pi;
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->sphere_mat, s->n_spheres))) return rc;
     d.sphere_mat = pi;
+    {
+        std::vector<uint32_t> identity(s->n_tris);
+        for (uint32_t i = 0; i < s->n_tris; i++) identity[i] = i;
+        uint32_t *po;
+        if ((rc = dev_upload(ctx, ctx->scene_allocs, &po, identity.data(), identity.size()))) return rc;
+        d.tri_order = po;
+        for (const DeviceBuild &b : builds) {
+            TriBvhResult res{};
+            std::string err;
+            if (build_tri_bvh_device(ctx->stream, const_cast<float4 *>(d.tri_hot) + 3 * (size_t)b.prim_first, const_cast<float4 *>(d.tri_cold) + 6 * (size_t)b.prim_first,
+                                     const_cast<int32_t *>(d.tri_mat) + b.prim_first, b.n, const_cast<float4 *>(d.wide) + 4 * (size_t)b.wide_first, po + b.prim_first, &res,
+                                     err))
+                return fail(ctx, PT_ERR_HIP, "device BVH build of set %u: %s", b.set, err.c_str());
+            DevBuffer &t = sets[b.set].tris;
+            t.root_ref = res.root_ref;
+            std::memcpy(t.rmin, res.rmin, 12);
+            std::memcpy(t.rmax, res.rmax, 12);
+            depth_of[b.set][0] = res.height;
+            for (int k = 0; k < 3; k++) boxes_finite = boxes_finite && std::isfinite(res.rmin[k]) && std::isfinite(res.rmax[k]);
+        }
+    }
+    // stack entries a ray can hold at once: one per level of the BVH it is in, plus, inside
+    // an instance, those of the instance BVH above it
+    {
+        auto set_depth = [&](uint32_t k) { return std::max(depth_of[k][0], std::max(depth_of[k][1], depth_of[k][2])); };
+        uint32_t child_depth = 0;
+        for (uint32_t k = 2; k < s->n_sets; k++) child_depth = std::max(child_depth, set_depth(k));
+        // + the newest entry kept in registers, + the two records an instance descent leaves on the stack
+        ctx->stack_need = std::max(set_depth(0), depth_of[0][3] + child_depth) + 4u;
+        ctx->wide_ok = wide_ok;
+    }
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->quad_mat, s->n_quads))) return rc;
     d.quad_mat = pi;
     float *pf;
@@ -1958,6 +1996,15 @@ int pt_read_rgb8(pt_context *ctx, uint8_t *rgb) {
     hipLaunchKernelGGL(k_tonemap, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->accum, ctx->rgb8, npix, (float)ctx->n_samples);
     HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->rgb8, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_read_triangle_order(pt_context *ctx, uint32_t *order, uint32_t n) {
+    if (!ctx || !order) return fail(ctx, PT_ERR_INVALID, "pt_read_triangle_order: NULL argument");
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "no scene uploaded");
+    if (n != ctx->scene.n_tris) return fail(ctx, PT_ERR_INVALID, "the scene has %u triangles, not %u", ctx->scene.n_tris, n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n) HIP_TRY(ctx, hipMemcpy(order, ctx->scene.tri_order, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

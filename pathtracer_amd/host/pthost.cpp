@@ -384,9 +384,10 @@ void PrimitiveBuffer::add_triangle(Triangle t) { bbox = bbox.merge(t.bbox()); tr
 void PrimitiveBuffer::add_sphere(Sphere s) { bbox = bbox.merge(s.bbox()); spheres.push(std::move(s)); }
 void PrimitiveBuffer::add_quad(Quad q) { bbox = bbox.merge(q.bbox()); quads.push(std::move(q)); }
 void PrimitiveBuffer::add_instance(Instance i) { bbox = bbox.merge(i.bbox()); instances.push(std::move(i)); }
-void PrimitiveBuffer::build_bvh() {
+void PrimitiveBuffer::build_bvh(size_t skip_tris_from) {
     const char *msg = "BVHBuilder::build failed: tree deeper than 63 levels";
-    if (triangles.len() > 0 && !BVHBuilder::build(triangles)) throw std::runtime_error(msg);
+    const bool skip = skip_tris_from != 0 && triangles.len() >= skip_tris_from;
+    if (triangles.len() > 0 && !skip && !BVHBuilder::build(triangles)) throw std::runtime_error(msg);
     if (spheres.len() > 0 && !BVHBuilder::build(spheres)) throw std::runtime_error(msg);
     if (quads.len() > 0 && !BVHBuilder::build(quads)) throw std::runtime_error(msg);
     if (instances.len() > 0 && !BVHBuilder::build(instances)) throw std::runtime_error(msg);
@@ -746,6 +747,7 @@ struct SrcLoader {
     std::vector<TextureRef> tex;
     std::vector<MaterialRef> mat;
     std::vector<std::shared_ptr<const RgbImage>> img;
+    size_t skip_tris_from = 0;  // PrimitiveBuffer::build_bvh
 
     explicit SrcLoader(const pts_scene &sc) : s(sc) {}
 
@@ -852,7 +854,7 @@ struct SrcLoader {
             }
             out.add_instance(std::move(inst));
         }
-        if (ps.build_bvh) out.build_bvh();
+        if (ps.build_bvh) out.build_bvh(skip_tris_from);
     }
 };
 }  // namespace
@@ -860,6 +862,10 @@ struct SrcLoader {
 extern "C" {
 
 pth_scene *pth_scene_build(const pts_scene *scene, const pts_camera *camera, char *err, size_t errlen) {
+    return pth_scene_build_opts(scene, camera, 0, err, errlen);
+}
+
+pth_scene *pth_scene_build_opts(const pts_scene *scene, const pts_camera *camera, uint32_t skip_tri_bvh_from, char *err, size_t errlen) {
     auto put_err = [&](const char *msg) {
         if (err && errlen) {
             std::strncpy(err, msg, errlen - 1);
@@ -874,6 +880,7 @@ pth_scene *pth_scene_build(const pts_scene *scene, const pts_camera *camera, cha
         if (scene->n_sets < 2) throw std::runtime_error("need at least the object set and the light set");
         auto out = std::make_unique<pth_scene>();
         SrcLoader L(*scene);
+        L.skip_tris_from = skip_tri_bvh_from;
         L.load_tables();
         // register tables first so that material / texture indices equal the description's
         for (const TextureRef &t : L.tex) out->flat.texture_index(t);

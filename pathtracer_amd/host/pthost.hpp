@@ -231,7 +231,9 @@ struct PrimitiveBuffer {  // src/objects.rs:130-206
     void add_instance(Instance i);
     // Builds one BVH per non-empty typed buffer. Throws std::runtime_error where the reference
     // panics (a tree deeper than 63 levels, src/bvh.rs:484-486 + src/objects.rs:172).
-    void build_bvh();
+    // skip_tris_from: triangle buffers with at least this many triangles are left without a BVH, for a
+    // device library that builds its own (0: every buffer gets one, as in src/objects.rs:165-189)
+    void build_bvh(size_t skip_tris_from = 0);
     size_t len() const { return triangles.len() + spheres.len() + quads.len() + instances.len(); }
 };
 
