@@ -40,7 +40,7 @@ check-lib: pathtracer_amd/libptcore_check.so
 
 # Register / LDS / scratch use of every kernel (no output file).
 resources:
-	$(HIPCC) $(filter-out -shared -fPIC,$(HIPFLAGS)) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage -o /dev/null $(CORE_SRC) 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* //' | paste - - - - - -
+	$(HIPCC) $(filter-out -shared -fPIC,$(HIPFLAGS)) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage -o /dev/null pathtracer_amd/csrc/ptcore.hip 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* //' | paste - - - - - -
 .PHONY: resources check-lib
 
 # Microbenchmarks behind design decisions (run on the GPU box).

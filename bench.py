@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--tail-below", type=int, default=-1)
     ap.add_argument("--rolling", type=int, default=12_000_000,
                     help="paths started per launch of the rolling schedule (0: one batch at a time per pipe; -1: library default)")
+    ap.add_argument("--integrator", default="reference", choices=["reference", "nee"],
+                    help="nee: next-event estimation with shadow rays (not in the reference); no counted pass, so no roofline figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -78,7 +80,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -108,6 +110,8 @@ def main():
         r.set_option(PT_OPT_TAIL_BELOW, args.tail_below)
     if args.rolling >= 0:
         r.set_option(PT_OPT_ROLLING, args.rolling)
+    if args.integrator == "nee":
+        r.set_option(PT_OPT_INTEGRATOR, 1)
     total_strata = r.sqrt_spp * r.sqrt_spp
     lo, hi = stratum_ranges(total_strata, world)[rank]
     S = min(S, hi - lo)
@@ -158,6 +162,8 @@ def main():
         img = r.read_rgb8()
         # traversal work per ray on this rank's last step, counted by the device in the reference's order
         r.stats_reset()
+        if args.integrator == "nee":  # the counters exist for the reference's estimator only: its rays stand in
+            r.set_option(PT_OPT_INTEGRATOR, 0)
         r.set_option(PT_OPT_COUNTERS, 1)
         r.reset_accum()
         step(args.warmup)
@@ -195,6 +201,7 @@ def main():
                                    + (" (procedural stand-in for mitsuba_smooth.obj, Disney + Lambertian + emitter)" if args.scene == "knob" else "")
                                    + f", {S} full-frame strata per step per GPU",
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce",
+                       "integrator": args.integrator,
                        "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
                                     "library default" if args.rolling < 0 else "one batch at a time per pipe")},
             "roofline": {"bound": "hbm", "kernel": "k_extend_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -175,6 +175,11 @@ enum {
                                            tree from the host builder's: same closest distances, the winner among exact
                                            ties may differ; triangles are reordered, see pt_read_triangle_order);
                                            0 = never (default): such buffers are searched in order */
+    PT_OPT_INTEGRATOR = 12,             /* 0 (default): the reference's estimator, Camera::ray_color (src/camera.rs:262-373);
+                                           1: next-event estimation, not in the reference: one LightBuffer::sample
+                                           direction per non-specular vertex tested with a shadow ray, the path continued
+                                           by BSDF sampling, balance heuristic between the two; BSDF_SAMPLE_PROBABILITY
+                                           is not used */
     PT_OPT_TAIL_BELOW = 9               /* once a bounce is expected to carry fewer rays than this, one launch finishes the
                                            batch instead of per-bounce launches; 0 = never (default:
                                            measured no faster on the benchmark scenes) */

@@ -210,6 +210,18 @@ struct Triangle {
         V3 u = position(1) - position(0), v = position(2) - position(0);
         return 2.0f / norm(cross(u, v));
     }
+    // Not in the reference: the density over directions that `sample` really has (the reference's pdf above
+    // is 1 / area, a density over the triangle); only the next-event estimator uses it.
+    float pdf_solid_angle(const Ray &ray) const {
+        Ray r = ray;
+        HitRecord rec;
+        if (!hit(r, rec)) return 0.0f;
+        V3 n = cross(position(1) - position(0), position(2) - position(0));
+        float nn = norm(n);
+        float distance_squared = rec.t * rec.t * norm_squared(ray.direction);
+        float cosine = std::fabs(dot(ray.direction, n)) / (norm(ray.direction) * nn);
+        return distance_squared / (cosine * (0.5f * nn));
+    }
     V3 sample(Rng &rng, V3 origin) const {  // :263-277
         float s = rng.range(0.0f, 1.0f), t = rng.range(0.0f, 1.0f);
         V3 u = position(1) - position(0), v = position(2) - position(0);
@@ -293,6 +305,17 @@ struct Sphere {
         float distance_squared = norm_squared(direction);
         ONB uvw = ONB::make(direction);
         return uvw.to_world(random_to_sphere(rng, radius, distance_squared));
+    }
+    // Not in the reference: `sample` puts the cone of random_to_sphere around the basis' third axis, while
+    // OrthonormalBasis::new puts the direction it is given on the second (src/types/onb.rs), so the reference's
+    // samples point sideways and do not have the density `pdf` reports.  This one swaps the two components;
+    // only the next-event estimator uses it.
+    V3 sample_towards(Rng &rng, V3 origin) const {
+        V3 direction = center - origin;
+        float distance_squared = norm_squared(direction);
+        ONB uvw = ONB::make(direction);
+        V3 c = random_to_sphere(rng, radius, distance_squared);
+        return uvw.to_world(v3(c.x, c.z, c.y));
     }
 };
 
@@ -643,12 +666,29 @@ struct LightBuffer {
         if (i < nt + ns + nq) return objects.quads.buffer[i - nt - ns].sample(rng, origin);
         return v3(0, 0, 0);  // Instance uses the trait default (:100-102)
     }
+    V3 sample_nee(Rng &rng, V3 origin) const {  // the same with Sphere::sample_towards
+        size_t n = objects.len();
+        size_t i = (size_t)rng.below(n);
+        size_t nt = objects.triangles.len(), ns = objects.spheres.len(), nq = objects.quads.len();
+        if (i < nt) return objects.triangles.buffer[i].sample(rng, origin);
+        if (i < nt + ns) return objects.spheres.buffer[i - nt].sample_towards(rng, origin);
+        if (i < nt + ns + nq) return objects.quads.buffer[i - nt - ns].sample(rng, origin);
+        return v3(0, 0, 0);
+    }
     float pdf(const Ray &ray) const {  // :259-278
         float pdf = 0.0f;
         for (const auto &t : objects.triangles.buffer) pdf += t.pdf(ray);
         for (const auto &s : objects.spheres.buffer) pdf += s.pdf(ray);
         for (const auto &q : objects.quads.buffer) pdf += q.pdf(ray);
         for (size_t i = 0; i < objects.instances.len(); i++) pdf += 0.0f;  // trait default (:97-99)
+        return pdf / (float)objects.len();
+    }
+    float pdf_nee(const Ray &ray) const {  // the same with Triangle::pdf_solid_angle
+        float pdf = 0.0f;
+        for (const auto &t : objects.triangles.buffer) pdf += t.pdf_solid_angle(ray);
+        for (const auto &s : objects.spheres.buffer) pdf += s.pdf(ray);
+        for (const auto &q : objects.quads.buffer) pdf += q.pdf(ray);
+        for (size_t i = 0; i < objects.instances.len(); i++) pdf += 0.0f;
         return pdf / (float)objects.len();
     }
 };

@@ -215,6 +215,93 @@ struct Scene {
             depth -= 1;
         }
     }
+
+    // ---- not in the reference: next-event estimation with one LightBuffer::sample direction and the
+    // balance heuristic at the vertices whose material has a scattering_pdf that is the density of its
+    // scatter (Lambertian, DisneyDiffuse, DisneySheen; tests/test_material_pdfs.py); the other non-specular
+    // materials are handled as ray_color handles them with BSDF_SAMPLE_PROBABILITY = 1.  This is the CPU
+    // statement, operation for operation, of the estimator PT_OPT_INTEGRATOR = 1 of the device library
+    // runs.  Radiance is summed along the path in the order it is found.  prev_pdf: density with which
+    // the current ray was drawn at a vertex with light sampling, 0 otherwise.
+    Color ray_color_nee(Rng &rng, Ray ray, uint32_t max_depth, uint64_t *rays) const {
+        Color L = gray(0.0f), beta = gray(1.0f);
+        float prev_pdf = 0.0f;
+        uint32_t depth = max_depth;
+        for (;;) {
+            if (depth == 0) return L;
+            if (rays) (*rays)++;
+            HitRecord rec;
+            if (!objects.hit(ray, rec)) return L + cmul(beta, camera.background);
+            const Material *material = mat(rec.material);
+            if (!material) return L;
+            if (material->is_emissive()) {
+                float w = 1.0f;
+                if (prev_pdf > 0.0f && prev_pdf < INFINITY) w = prev_pdf / (prev_pdf + lights.pdf_nee(ray));
+                return L + cmul(beta, shading.emitted(*material, rec)) * w;
+            }
+            ONB surface = ONB::make(rec.normal);
+            V3 w_out = -normalize(surface.to_local(ray.direction));
+            if (material->is_specular()) {
+                V3 w_in = shading.scatter(*material, rng, w_out, rec);
+                beta = cmul(beta, shading.bsdf_evaluate(*material, w_out, w_in, rec));
+                ray = Ray::make(rec.p, surface.to_world(w_in));
+                prev_pdf = 0.0f;
+                depth -= 1;
+                continue;
+            }
+            const bool light_sampling = material->type == PTS_MAT_LAMBERTIAN || material->type == PTS_MAT_DISNEY_DIFFUSE ||
+                                        material->type == PTS_MAT_DISNEY_SHEEN;
+            if (!light_sampling) {  // ray_color's vertex with P = 1
+                (void)rng.gen_bool(1.0);
+                V3 w_in = shading.scatter(*material, rng, w_out, rec);
+                V3 w_in_world = surface.to_world(w_in);
+                float scatter_pdf = shading.scattering_pdf(*material, w_out, w_in, rec);
+                float light_pdf = lights.pdf(Ray::make(rec.p, w_in_world));
+                float pdf = 1.0f * scatter_pdf + (1.0f - 1.0f) * light_pdf;
+                Color bsdf = shading.bsdf_evaluate(*material, w_out, w_in, rec);
+                float cosv = std::fabs(w_in.y);
+                Color throughput = (bsdf * cosv) / pdf;
+                float weight = 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
+                if (weight != weight || rng.gen_bool((double)weight)) return L;
+                beta = cmul(beta, throughput / (1.0f - weight));
+                prev_pdf = 0.0f;
+                ray = Ray::make(rec.p, w_in_world);
+                depth -= 1;
+                continue;
+            }
+            if (lights.objects.len() != 0) {
+                V3 ls = lights.sample_nee(rng, rec.p);
+                Ray shadow = Ray::make(rec.p, ls);
+                float lp = lights.pdf_nee(shadow);
+                if (lp > 0.0f && lp < INFINITY) {
+                    V3 wl = normalize(surface.to_local(ls));
+                    float sp = shading.scattering_pdf(*material, w_out, wl, rec);
+                    if (sp > 0.0f) {
+                        Color f = shading.bsdf_evaluate(*material, w_out, wl, rec) * std::fabs(wl.y);
+                        Color c = cmul(beta, f) / (lp + sp);
+                        if (rays) (*rays)++;
+                        HitRecord srec;
+                        if (objects.hit(shadow, srec)) {
+                            const Material *m2 = mat(srec.material);
+                            if (m2 && m2->is_emissive() && srec.front_face) L = L + cmul(c, shading.emitted(*m2, srec));
+                        }
+                    }
+                }
+            }
+            V3 w_in = shading.scatter(*material, rng, w_out, rec);
+            V3 w_in_world = surface.to_world(w_in);
+            float sp = shading.scattering_pdf(*material, w_out, w_in, rec);
+            Color bsdf = shading.bsdf_evaluate(*material, w_out, w_in, rec);
+            float cosv = std::fabs(w_in.y);
+            Color throughput = (bsdf * cosv) / sp;
+            float weight = 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
+            if (weight != weight || rng.gen_bool((double)weight)) return L;
+            beta = cmul(beta, throughput / (1.0f - weight));
+            prev_pdf = sp;
+            ray = Ray::make(rec.p, w_in_world);
+            depth -= 1;
+        }
+    }
 };
 
 // src/types/color.rs:36-42, :68-78
@@ -313,7 +400,7 @@ struct RenderOptions {
     uint32_t stratum_begin, stratum_end;
     uint64_t seed;
     uint32_t threads;
-    int iterative;          // 0 = recursive form (the reference's), 1 = unrolled form
+    int iterative;          // 0 = recursive form (the reference's), 1 = unrolled form, 2 = next-event estimation (ray_color_nee)
     int tonemap_each_pass;  // reference refreshes the whole 8-bit image after every pass
 };
 
@@ -384,8 +471,9 @@ inline void render(const Scene &sc, const RenderOptions &o, float *accum /*W*H*3
                     Rng rng = Rng::for_sample(o.seed, (uint32_t)i, stratum);
                     size_t u = i % cam.image_width, v = i / cam.image_width;
                     Ray ray = cam.get_ray(rng, (float)u, (float)v, (float)s_u, (float)s_v);
-                    Color c = o.iterative ? sc.ray_color_iterative(rng, ray, cam.max_depth, &rays)
-                                          : sc.ray_color(rng, ray, cam.max_depth, &rays);
+                    Color c = o.iterative == 2 ? sc.ray_color_nee(rng, ray, cam.max_depth, &rays)
+                              : o.iterative ? sc.ray_color_iterative(rng, ray, cam.max_depth, &rays)
+                                            : sc.ray_color(rng, ray, cam.max_depth, &rays);
                     if (per_sample) {
                         float *ps = per_sample + ((size_t)(stratum - o.stratum_begin) * npix + i) * 3;
                         ps[0] = c.x; ps[1] = c.y; ps[2] = c.z;

@@ -102,7 +102,9 @@ constexpr uint32_t CTL_RAY_CHUNKS = 0;    // +parity: chunks in ray queue [parit
 constexpr uint32_t CTL_RAY_CURSOR = 2;    // +parity: 64-entry pieces of ray queue [parity] handed out so far
 constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material queue [queue]
 constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
-constexpr uint32_t CTL_WORDS = (4 + 2 * MAX_QUEUES) * CTL_STRIDE;
+constexpr uint32_t CTL_SHADOW_CHUNKS = 4 + 2 * MAX_QUEUES;  // +parity: chunks in the shadow-ray queue filled during a step of that parity
+constexpr uint32_t CTL_SHADOW_CURSOR = 6 + 2 * MAX_QUEUES;  // +parity: its pieces handed out so far
+constexpr uint32_t CTL_WORDS = (8 + 2 * MAX_QUEUES) * CTL_STRIDE;
 
 // A launch may carry paths of several batches at once (each at a different bounce).  The slot
 // arrays are then cut into regions of region_cap slots, one batch per region, and a path's
@@ -117,7 +119,7 @@ struct RegionParams {  // 32 B
 struct PathState {
     float4 *ray_o;    // origin.xyz, rng draw counter (bits)
     float4 *ray_d;    // direction.xyz, remaining depth (bits)
-    float4 *beta;     // path throughput so far
+    float4 *beta;     // path throughput so far; w: density with which the current ray was drawn (next-event estimation only)
     float4 *hit;      // t, u, v, global primitive index (bits)
     uint32_t *hit2;   // type | (instance+1) << 2, or PTD_HIT_MISS
     float4 *contrib;  // radiance of the finished path (xyz)
@@ -134,6 +136,12 @@ struct PathState {
     int leaf_batch;            // lanes that must be waiting at a leaf before the wave runs a primitive test
     RegionParams *regions;     // [slots / region_cap] batches the regions hold (only where batches share launches)
     uint32_t region_cap;       // slots per region
+    // next-event estimation (PT_OPT_INTEGRATOR = 1): a vertex may leave a shadow ray behind, from the new
+    // ray origin (ray_o) along hit.xyz (hit is free between shading and the next closest-hit step); if it
+    // reaches an emitter, shadow_c times the emitted radiance is added to the path's contrib
+    uint32_t nee;
+    uint32_t *shadow_queue;
+    float4 *shadow_c;
 };
 
 }  // namespace ptd

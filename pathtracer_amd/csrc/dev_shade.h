@@ -491,6 +491,11 @@ __device__ inline float mat_pdf(const DevMaterial &m, f3 w_out, f3 w_in, const S
 
 // ---------------------------------------------------------------- lights (src/objects.rs:235-278)
 // pdf of one light for a ray: the primitive's `hit` on a copy of the ray, then its formula.
+// Triangle::pdf of the reference is 1 / area, a density over the triangle rather than over
+// directions (spheres and quads report a solid-angle density).  TRIS_BY_SOLID_ANGLE converts it,
+// distance^2 / (cosine * area) as Quad::pdf does; only the next-event estimator, which is not
+// part of the reference and needs the density Triangle::sample really has, asks for that.
+template <bool TRIS_BY_SOLID_ANGLE = false>
 __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
     float pdf = 0.0f;
     TravCounters tc{0, 0, 0, 0};
@@ -504,7 +509,15 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
         float term = 0.0f;
         if (h.code != PTD_HIT_MISS) {
             const float4 a = sc.tri_hot[3 * g], b = sc.tri_hot[3 * g + 1], c = sc.tri_hot[3 * g + 2];
-            term = 2.0f / norm(cross(mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x)));
+            const f3 n = cross(mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
+            if constexpr (TRIS_BY_SOLID_ANGLE) {
+                const float nn = norm(n);
+                const float distance_squared = r.t_max * r.t_max * norm_squared(d);
+                const float cosine = fabsf(dot(d, n)) / (norm(d) * nn);
+                term = distance_squared / (cosine * (0.5f * nn));
+            } else {
+                term = 2.0f / norm(n);
+            }
         }
         pdf += term;
     }
@@ -546,6 +559,11 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
 
 // LightBuffer::sample: uniform pick, then the primitive's sampler; returns the unnormalised
 // vector from `origin` towards the sampled point.
+// Sphere::sample of the reference puts its cone around the basis' third axis while
+// OrthonormalBasis::new puts the direction it is given on the second, so its samples point
+// sideways and do not have the density Sphere::pdf reports.  SPHERES_TOWARDS swaps the two
+// components; only the next-event estimator, which is not part of the reference, asks for that.
+template <bool SPHERES_TOWARDS = false>
 __device__ inline f3 light_sample(const DevScene &sc, Rng &rng, f3 origin) {
     const DevSet &L = sc.lights;
     uint32_t i = rng.below(sc.n_light_total);
@@ -568,7 +586,8 @@ __device__ inline f3 light_sample(const DevScene &sc, Rng &rng, f3 origin) {
         float phi = 2.0f * PTD_PI * r1;
         float x = cosf(phi) * sqrtf(1.0f - z * z);
         float y = sinf(phi) * sqrtf(1.0f - z * z);
-        return to_world(uvw, mk3(x, y, z) * sp.w);
+        const f3 c = mk3(x, y, z) * sp.w;
+        return SPHERES_TOWARDS ? to_world(uvw, mk3(c.x, c.z, c.y)) : to_world(uvw, c);
     }
     if (i < nt + ns + nq) {  // Quad::sample, quad_mesh.rs:176-179
         const uint32_t g = L.quads.prim_first + (i - nt - ns);

@@ -182,10 +182,13 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
         }
         if (mat >= 0) {
             qslot = sc.mat_queue[mat];
-        } else {
+        } else if (!ps.nee) {
             const float4 b = ps.beta[slot];
             const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
             ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+        } else if (code == PTD_HIT_MISS) {  // contrib already holds the light samples of the earlier vertices
+            const float4 b = ps.beta[slot], c = ps.contrib[slot];
+            ps.contrib[slot] = make_float4(c.x + b.x * background.x, c.y + b.y * background.y, c.z + b.z * background.z, 0.0f);
         }
     }
     // one pass per material queue that some lane of this wave needs
@@ -357,8 +360,22 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
 // multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
 // type MT; `local` is its number within its batch.  Returns true when the path goes on: its
 // next ray is then in ps.ray_o / ps.ray_d.
-template <int MT>
-__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local) {
+//
+// NEE selects the integrator that is not in the reference (PT_OPT_INTEGRATOR = 1): next-event
+// estimation with one light sample per vertex and the balance heuristic, at the vertices whose
+// material has a scattering_pdf that is the density of its scatter (Lambertian, DisneyDiffuse,
+// DisneySheen: checked numerically in tests/test_material_pdfs.py; for the other Disney lobes of
+// the reference it is not, so no combination of the two samplers can reproduce what the
+// reference's estimator converges to, and those vertices are handled exactly as the reference
+// does, with BSDF sampling alone).  At a vertex with light sampling a direction is drawn with
+// LightBuffer::sample; when its density lp is positive and finite and the BSDF sampler could
+// have produced it (sp > 0), shadow = true and the path leaves (direction, beta * f * |cos| /
+// (lp + sp)) in ps.hit / ps.shadow_c for the shadow-ray kernel.  The path itself continues by
+// BSDF sampling with the reference's roulette; an emitter found that way counts with weight
+// sp' / (sp' + lp'), and fully after the camera or a vertex without light sampling.  Radiance is
+// added to ps.contrib as it is found; paths that end without finding any add nothing.
+template <int MT, bool NEE>
+__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow) {
     const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
     const uint32_t code = ps.hit2[slot];
     const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
@@ -366,11 +383,20 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
     uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
     const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code);
     const DevMaterial m = sc.mats[s.material];
+    shadow = false;
     if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
         // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
         f3 e = mk3(0.0f, 0.0f, 0.0f);
         if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v);
-        ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
+        if constexpr (NEE) {
+            float w = 1.0f;
+            if (b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true>(sc, ro, rd));
+            const float4 c = ps.contrib[slot];
+            const f3 add = cmul(beta, e) * w;
+            ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
+        } else {
+            ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
+        }
     } else {
         uint32_t pixel, stratum;
         slot_to_sample(bp, local, pixel, stratum);
@@ -380,12 +406,42 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
         const f3 w_out = -normalize(to_local(surface, rd));
         f3 w_in_world;
         bool go_on = true;
+        float drawn_with = 0.0f;  // NEE: density of the ray that leaves this vertex, 0 = specular
         if constexpr (MT == PTS_MAT_METAL || MT == PTS_MAT_DIELECTRIC) {
             // purely specular: no pdf, no roulette (camera.rs:298-313)
             const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
             const f3 attenuation = mat_eval<MT>(sc, m, w_out, w_in, s);
             w_in_world = to_world(surface, w_in);
             beta = cmul(beta, attenuation);
+        } else if constexpr (NEE && (MT == PTS_MAT_LAMBERTIAN || MT == PTS_MAT_DISNEY_DIFFUSE || MT == PTS_MAT_DISNEY_SHEEN)) {
+            if (sc.n_light_total != 0u) {
+                const f3 ls = light_sample<true>(sc, rng, s.p);
+                const float lp = light_pdf<true>(sc, s.p, ls);
+                if (lp > 0.0f && lp < INFINITY) {
+                    const f3 wl = normalize(to_local(surface, ls));
+                    const float sp = mat_pdf<MT>(m, w_out, wl, s);
+                    if (sp > 0.0f) {
+                        const f3 f = mat_eval<MT>(sc, m, w_out, wl, s) * fabsf(wl.y);
+                        const f3 c = cmul(beta, f) / (lp + sp);
+                        ps.hit[slot] = make_float4(ls.x, ls.y, ls.z, 0.0f);
+                        ps.shadow_c[slot] = make_float4(c.x, c.y, c.z, 0.0f);
+                        shadow = true;
+                    }
+                }
+            }
+            const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
+            w_in_world = to_world(surface, w_in);
+            const float sp = mat_pdf<MT>(m, w_out, w_in, s);
+            const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
+            const float cosv = fabsf(w_in.y);
+            const f3 throughput = (bsdf * cosv) / sp;
+            const float weight = 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
+            if (weight != weight || rng.gen_bool(weight)) {
+                go_on = false;
+            } else {
+                beta = cmul(beta, throughput / (1.0f - weight));
+                drawn_with = sp;
+            }
         } else {
             // mixture of BSDF sampling and light sampling (camera.rs:317-357)
             f3 w_in;
@@ -418,14 +474,15 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
             depth -= 1u;
             if (depth == 0u) {
                 // the next ray_color call returns zeros without tracing (camera.rs:271-273)
-                ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
+                if constexpr (!NEE) ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
             } else {
                 ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
                 ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
-                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, drawn_with);
                 return true;
             }
         }
+        if (NEE && shadow) ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, 0.0f);  // the shadow ray still starts here
     }
     return false;
 }
@@ -433,19 +490,20 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
 // shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
 // ROLL: the queue mixes batches, `bp` holds what they have in common and the rest comes from the
 // path's region.
-template <int MT, bool ROLL>
+template <int MT, bool ROLL, bool NEE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
     const uint32_t *queue = ps.shade_queue[q];
-    WavePush out;
+    WavePush out, shadows;
     out.init();
-    uint32_t survivors = 0u;
+    shadows.init();
+    uint32_t survivors = 0u;  // rays this launch starts: next-bounce rays and shadow rays
     const PieceWalk pw = piece_walk(n_chunks);
     for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
         const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        bool alive = false;
+        bool alive = false, shadow = false;
         if (slot != QUEUE_EMPTY) {
             if constexpr (ROLL) {
                 const uint32_t region = slot / ps.region_cap;
@@ -454,23 +512,71 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
                 mine.seed_mixed = rp.seed_mixed;
                 mine.stratum_first = rp.stratum_first;
                 mine.n_strata = rp.n_strata;
-                alive = shade_vertex<MT>(sc, ps, mine, slot, slot - region * ps.region_cap);
+                alive = shade_vertex<MT, NEE>(sc, ps, mine, slot, slot - region * ps.region_cap, shadow);
             } else {
-                alive = shade_vertex<MT>(sc, ps, bp, slot, slot);
+                alive = shade_vertex<MT, NEE>(sc, ps, bp, slot, slot, shadow);
             }
         }
         if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
             survivors += (uint32_t)__popcll(__ballot(alive));
             wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
+            if constexpr (NEE) {
+                survivors += (uint32_t)__popcll(__ballot(shadow));
+                wave_push(shadows, shadow, slot, ps.shadow_queue, &ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE]);
+            }
         }
     }
     if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
         wave_push_close(out, ps.ray_queue[parity ^ 1u]);
-        if (survivors && lane_id() == 0u) {  // rays of the next bounce
+        if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
+        if (survivors && lane_id() == 0u) {
             atomicAdd(&stats->rays_total, (unsigned long long)survivors);
-            if (!ROLL && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
+            if (!ROLL && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
         }
     }
+}
+
+// Shadow rays of one step (next-event estimation): closest hit along each, and where that is an
+// emitter, its radiance times the factor the vertex left behind goes to the path.
+template <bool INSTANCES>
+__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
+    const uint32_t parity = bounce & 1u;
+    const uint32_t n_chunks = ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the shading of the next step
+        ps.ctl[(CTL_SHADOW_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
+        ps.ctl[(CTL_SHADOW_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
+    }
+    if (n_chunks == 0u) return;
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    const uint32_t *queue = ps.shadow_queue;
+    walk_world<INSTANCES>(
+        sc, n_chunks * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_SHADOW_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+        [&](uint32_t i, uint32_t &slot, TravRay &r) {
+            slot = queue[i];
+            if (slot == QUEUE_EMPTY) return false;
+            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
+            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            return true;
+        },
+        [&](uint32_t slot, f3 &o, f3 &d) {
+            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
+            o = mk3(ro.x, ro.y, ro.z);
+            d = mk3(rd.x, rd.y, rd.z);
+        },
+        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
+            if (!done || h.code == PTD_HIT_MISS) return;
+            const uint32_t type = h.code & 3u;
+            const int32_t mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
+            if (mat < 0 || sc.mats[mat].type != PTS_MAT_DIFFUSE_LIGHT) return;
+            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
+            const Surf s = make_surf(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), r.t_max, h.u, h.v, h.prim, h.code);
+            if (!s.front_face) return;
+            const f3 e = tex_value(sc, sc.mats[mat].texture, s.u, s.v);
+            const float4 f = ps.shadow_c[slot], c = ps.contrib[slot];
+            const f3 add = cmul(mk3(f.x, f.y, f.z), e);
+            ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
+        });
 }
 
 // Everything that is left of a batch from bounce `bounce` on, in one launch: each lane takes a
@@ -511,18 +617,18 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, Batch
             }
             ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
             ps.hit2[slot] = h.code;
-            bool alive = false;
+            bool alive = false, shadow;
             switch (sc.mats[mat].type) {
-                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT>(sc, ps, bp, slot, slot); break;
-                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN>(sc, ps, bp, slot, slot); break;
+                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN, false>(sc, ps, bp, slot, slot, shadow); break;
                 default: break;
             }
             if (!alive) break;
@@ -685,6 +791,7 @@ struct pt_context {
     int blocks_per_cu = 4;
 #endif
     int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
+    bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
     uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
     int tail_below = 0;  // rays under which the rest of a batch goes to one launch (0: never)
 
@@ -1035,6 +1142,16 @@ int pt_set_option(pt_context *ctx, int key, double value) {
                 pp.capacity = 0;
             }
             for (auto &r : ctx->rolls) free_roll(ctx, r);
+            return PT_OK;
+        case PT_OPT_INTEGRATOR:
+            if (value != 0.0 && value != 1.0) return fail(ctx, PT_ERR_INVALID, "integrator must be 0 (the reference's) or 1 (next-event estimation)");
+            ctx->nee = value != 0.0;
+            for (auto &pp : ctx->pipes) {  // the shadow-ray queue exists only with next-event estimation
+                free_pool(ctx, pp.allocs);
+                pp.capacity = 0;
+            }
+            for (auto &r : ctx->rolls) free_roll(ctx, r);
+            forget_bounce_profile(ctx);
             return PT_OK;
         case PT_OPT_DEVICE_BVH:
             if (!(value >= 0.0 && value <= 4.0e9)) return fail(ctx, PT_ERR_INVALID, "triangle count out of range");
@@ -1472,6 +1589,11 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
+    ps.nee = ctx->nee ? 1u : 0u;
+    if (ctx->nee) {
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_queue, max_chunks * QUEUE_CHUNK))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_c, n_slots))) return rc;
+    }
     // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
     ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
     const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
@@ -1513,6 +1635,11 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
 #undef EXI
 }
 
+static void launch_shadow(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce) {
+    if (ctx->scene.world.insts.prim_count != 0) hipLaunchKernelGGL((k_shadow_walk<true>), dim3(grid), dim3(BLOCK), 0, st, ctx->scene, ps, bounce, ctx->stats);
+    else hipLaunchKernelGGL((k_shadow_walk<false>), dim3(grid), dim3(BLOCK), 0, st, ctx->scene, ps, bounce, ctx->stats);
+}
+
 struct ShadeLaunch {
     pt_context *ctx;
     hipStream_t st;
@@ -1524,8 +1651,13 @@ struct ShadeLaunch {
 };
 template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
-    if (l.roll) hipLaunchKernelGGL((k_shade<MT, true>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats);
-    else hipLaunchKernelGGL((k_shade<MT, false>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats);
+#define SHADE(R, N) hipLaunchKernelGGL((k_shade<MT, R, N>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats)
+    if (l.ps->nee) {
+        if (l.roll) SHADE(true, true); else SHADE(false, true);
+    } else {
+        if (l.roll) SHADE(true, false); else SHADE(false, false);
+    }
+#undef SHADE
 }
 static void launch_shade_type(int type, const ShadeLaunch &l) {
     switch (type) {
@@ -1591,7 +1723,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     harvest_set(ctx, pp, (int)(pp.batches & 1u));  // the set this batch is about to record into
     int rc = ensure_paths(ctx, pp, n_slots);
     if (rc) return rc;
-    BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->bsdf_prob};
+    BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->nee ? 1.0f : ctx->bsdf_prob};
     hipStream_t st = pp.stream;
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.bounce_rays, 0, BOUNCE_PROFILE_LEN * sizeof(uint32_t), st));
@@ -1613,7 +1745,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     };
     // From the first bounce expected to carry fewer than tail_below rays, one launch finishes the batch.
     uint32_t tail_from = depth;
-    if (ctx->tail_below > 0 && !ctx->counters)
+    if (ctx->tail_below > 0 && !ctx->counters && !ctx->nee)
         for (uint32_t b = 1; b < depth; b++) {
             const uint64_t e = expected(b);
             if (e == 0) break;
@@ -1643,6 +1775,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
         launch_extend(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
         for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, q});
+        if (ctx->nee) launch_shadow(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
     if (bounces_out) *bounces_out = bounces;
@@ -1676,6 +1809,11 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
     if ((rc = dev_alloc(ctx, r.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.regions, (size_t)n_regions))) return rc;
+    ps.nee = ctx->nee ? 1u : 0u;
+    if (ctx->nee) {
+        if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_queue, max_chunks * QUEUE_CHUNK))) return rc;
+        if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_c, total))) return rc;
+    }
     HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), pp.stream));
     HIP_TRY(ctx, hipMemsetAsync(ps.regions, 0, n_regions * sizeof(RegionParams), pp.stream));
     ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
@@ -1692,7 +1830,7 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
 // Bytes ensure_roll allocates per pipe, near enough.
 static uint64_t roll_bytes(const pt_context *ctx, uint64_t n_regions, uint64_t cap) {
     const uint64_t total = n_regions * cap;
-    return total * 84u + (total + total / 3u) * 4u * (2u + ctx->n_queues);
+    return total * (ctx->nee ? 100u : 84u) + (total + total / 3u) * 4u * (2u + ctx->n_queues + (ctx->nee ? 1u : 0u));
 }
 
 static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
@@ -1742,9 +1880,10 @@ static int roll_step(pt_context *ctx, const BatchParams *nb) {
     if (prof) (void)hipEventRecord(r.prof[ring][2], st);
     BatchParams common{};
     common.npix = ctx->cam.width * ctx->cam.height;
-    common.bsdf_prob = ctx->bsdf_prob;
+    common.bsdf_prob = ctx->nee ? 1.0f : ctx->bsdf_prob;
     const int grid_shade = grid_fixed(ctx, bound, ctx->shade_blocks_per_cu);
     for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, true});
+    if (ctx->nee) launch_shadow(ctx, st, grid_fixed(ctx, bound), ps, parity);
     if (prof) {
         (void)hipEventRecord(r.prof[ring][3], st);
         r.prof_pending[ring] = true;
@@ -1798,6 +1937,8 @@ static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
     if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PT_ERR_STATE, "upload a scene and set a camera before rendering");
     const uint64_t total = (uint64_t)ctx->cam.sqrt_spp * ctx->cam.sqrt_spp;
     if (b > e || e > total) return fail(ctx, PT_ERR_INVALID, "stratum range [%u,%u) outside [0,%llu)", b, e, (unsigned long long)total);
+    if (ctx->nee && (ctx->counters || !ctx->use_wide()))
+        return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation runs on the ray-drawing traversal only (no test counters, no reference-order traversal)");
     return PT_OK;
 }
 
