@@ -40,6 +40,16 @@
 
 namespace ptd {
 
+// PT_TOP_LDS = N > 0: the first N nodes of the world's triangle tree (its top, breadth-first) are copied
+// to LDS by every workgroup and read from there.  Off by default: measured slower (see the numbers where
+// the kernels are described), the L1 already serves those nodes.
+#ifndef PT_TOP_LDS
+#define PT_TOP_LDS 0
+#endif
+#if PT_TOP_LDS > 0
+__shared__ float4 g_top_nodes[4 * PT_TOP_LDS];
+#endif
+
 // Stack / `cur` values that are not node references.  None can be a leaf reference: all
 // decode to 127 primitives at an offset of at least 2^24 - 4, past the largest offset a
 // leaf may have.
@@ -112,6 +122,12 @@ template <bool INSTANCES, class Source, class Reload, class Sink>
 __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces, uint32_t *cursor, int refill_below, int leaf_batch,
                                            LaneStack &st, unsigned long long *bad_refs, Source &&source, Reload &&reload, Sink &&sink) {
     const DevSet &set = sc.world;
+#if PT_TOP_LDS > 0
+    const uint32_t top_base = set.tris.wide_first;
+    const uint32_t top_n = set.tris.tree != 0u && sc.n_wide - top_base >= (uint32_t)PT_TOP_LDS ? (uint32_t)PT_TOP_LDS : 0u;
+    for (uint32_t i = threadIdx.x; i < 4u * top_n; i += blockDim.x) g_top_nodes[i] = sc.wide[4 * (size_t)top_base + i];
+    __syncthreads();
+#endif
     constexpr uint32_t PIECES = QUEUE_CHUNK / 64u;
     const uint32_t claim = n_pieces >= 2u * PIECES * wave_count() ? PIECES : 1u;  // pieces per atomic
     // the cursors live in memory every XCD shares: waves that cannot get a piece do not poll them
@@ -209,7 +225,16 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
             if (!(cur & WIDE_LEAF)) {
                 WALK_CHECK(node_base + cur < sc.n_wide, 1)
                 const float4 *w = sc.wide + 4 * (size_t)(node_base + cur);
+#if PT_TOP_LDS > 0
+                float4 a, b, c, d;
+                if (node_base == top_base && cur < top_n) {
+                    a = g_top_nodes[4 * cur], b = g_top_nodes[4 * cur + 1], c = g_top_nodes[4 * cur + 2], d = g_top_nodes[4 * cur + 3];
+                } else {
+                    a = w[0], b = w[1], c = w[2], d = w[3];
+                }
+#else
                 const float4 a = w[0], b = w[1], c = w[2], d = w[3];
+#endif
                 float el, er;
                 bool hl, hr;
                 if (plain) {
