@@ -32,7 +32,10 @@ extern "C" {
 enum {
     PTS_TEX_SOLID = 0,     /* Solid::new(albedo)                       color[] */
     PTS_TEX_CHECKERED = 1, /* Checkered::new(odd, even, inv_scale)     odd, even, scale */
-    PTS_TEX_IMAGE = 2      /* Image::new(Some(img)) / Image::load(..)  image (or -1 = load failed) */
+    PTS_TEX_IMAGE = 2,     /* Image::new(Some(img)) / Image::load(..)  image (or -1 = load failed) */
+    PTS_TEX_NOISE = 3      /* not in the reference: color * (1 + sin(scale * p.z + 10 * turbulence(p))) with
+                              gradient noise on the integer lattice, gradients hashed from `odd` (a seed)
+                              and the lattice point, 7 octaves; color[], scale, odd */
 };
 
 typedef struct pts_texture {

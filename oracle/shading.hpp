@@ -24,10 +24,54 @@ struct TextureTable {
     std::vector<uint8_t> texels;
 
     // src/textures.rs:59-103, src/textures/image.rs:31-65
+    // PTS_TEX_NOISE (not in the reference): gradient noise, 7 octaves; see include/ptscene_src.h
+    static int32_t f2i32(float f) {
+        if (f != f) return 0;
+        if (f >= 2147483648.0f) return INT32_MAX;
+        if (f <= -2147483648.0f) return INT32_MIN;
+        return (int32_t)f;
+    }
+    static V3 lattice_gradient(uint32_t seed, int32_t ix, int32_t iy, int32_t iz) {
+        uint64_t z = (uint64_t)seed ^ ((uint64_t)(uint32_t)ix * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)iy * 0xC2B2AE3D27D4EB4Full) ^
+                     ((uint64_t)(uint32_t)iz * 0x165667B19E3779F9ull);
+        z = mix64(z);
+        V3 g = v3((float)(uint32_t)(z & 0x1FFFFFull) / 1048576.0f - 1.0f, (float)(uint32_t)((z >> 21) & 0x1FFFFFull) / 1048576.0f - 1.0f,
+                  (float)(uint32_t)((z >> 42) & 0x1FFFFFull) / 1048576.0f - 1.0f);
+        float n2 = dot(g, g);
+        if (!(n2 > 0.0f)) return v3(1.0f, 0.0f, 0.0f);
+        return g / std::sqrt(n2);
+    }
+    static float noise(uint32_t seed, V3 p) {
+        float fx = std::floor(p.x), fy = std::floor(p.y), fz = std::floor(p.z);
+        int32_t ix = f2i32(fx), iy = f2i32(fy), iz = f2i32(fz);
+        float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+        float su = u * u * (3.0f - 2.0f * u), sv = v * v * (3.0f - 2.0f * v), sw = w * w * (3.0f - 2.0f * w);
+        float acc = 0.0f;
+        for (uint32_t di = 0; di < 2; di++)
+            for (uint32_t dj = 0; dj < 2; dj++)
+                for (uint32_t dk = 0; dk < 2; dk++) {
+                    V3 g = lattice_gradient(seed, (int32_t)((uint32_t)ix + di), (int32_t)((uint32_t)iy + dj), (int32_t)((uint32_t)iz + dk));
+                    V3 d = v3(u - (float)di, v - (float)dj, w - (float)dk);
+                    float weight = ((di ? su : 1.0f - su) * (dj ? sv : 1.0f - sv)) * (dk ? sw : 1.0f - sw);
+                    acc += weight * dot(g, d);
+                }
+        return acc;
+    }
+    static float turbulence(uint32_t seed, V3 p) {
+        float accum = 0.0f, weight = 1.0f;
+        for (int i = 0; i < 7; i++) {
+            accum += weight * noise(seed, p);
+            weight *= 0.5f;
+            p = p * 2.0f;
+        }
+        return std::fabs(accum);
+    }
+
     Color value(int32_t id, float u, float v, V3 p) const {
-        (void)p;
         const pts_texture &t = tex[(size_t)id];
         switch (t.type) {
+            case PTS_TEX_NOISE:
+                return v3(t.color[0], t.color[1], t.color[2]) * (1.0f + std::sin(t.scale * p.z + 10.0f * turbulence((uint32_t)t.odd, p)));
             case PTS_TEX_SOLID:
                 return v3(t.color[0], t.color[1], t.color[2]);
             case PTS_TEX_CHECKERED: {

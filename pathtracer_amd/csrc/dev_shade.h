@@ -18,11 +18,60 @@ struct Surf {
 };
 
 // ---------------------------------------------------------------- textures
+// PTS_TEX_NOISE, which the reference does not have (its README names the "Next Week" scene, whose
+// marble texture this is): gradient noise on the integer lattice.  The gradient of a lattice point
+// is the normalised vector of three 21-bit fields of mix64(seed, point), each mapped to [-1, 1).
+__device__ __forceinline__ int32_t f2i32_sat(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)f;
+}
+__device__ inline f3 noise_gradient(uint32_t seed, int32_t ix, int32_t iy, int32_t iz) {
+    uint64_t z = (uint64_t)seed ^ ((uint64_t)(uint32_t)ix * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)iy * 0xC2B2AE3D27D4EB4Full) ^
+                 ((uint64_t)(uint32_t)iz * 0x165667B19E3779F9ull);
+    z = mix64(z);
+    f3 g = mk3((float)(uint32_t)(z & 0x1FFFFFull) / 1048576.0f - 1.0f, (float)(uint32_t)((z >> 21) & 0x1FFFFFull) / 1048576.0f - 1.0f,
+               (float)(uint32_t)((z >> 42) & 0x1FFFFFull) / 1048576.0f - 1.0f);
+    const float n2 = dot(g, g);
+    if (!(n2 > 0.0f)) return mk3(1.0f, 0.0f, 0.0f);
+    return g / sqrtf(n2);
+}
+__device__ inline float noise_value(uint32_t seed, f3 p) {
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const int32_t ix = f2i32_sat(fx), iy = f2i32_sat(fy), iz = f2i32_sat(fz);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const float su = u * u * (3.0f - 2.0f * u), sv = v * v * (3.0f - 2.0f * v), sw = w * w * (3.0f - 2.0f * w);
+    float acc = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                const f3 g = noise_gradient(seed, (int32_t)((uint32_t)ix + (uint32_t)di), (int32_t)((uint32_t)iy + (uint32_t)dj), (int32_t)((uint32_t)iz + (uint32_t)dk));
+                const f3 d = mk3(u - (float)di, v - (float)dj, w - (float)dk);
+                const float weight = ((di ? su : 1.0f - su) * (dj ? sv : 1.0f - sv)) * (dk ? sw : 1.0f - sw);
+                acc += weight * dot(g, d);
+            }
+    return acc;
+}
+__device__ inline float noise_turbulence(uint32_t seed, f3 p) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < 7; i++) {
+        accum += weight * noise_value(seed, p);
+        weight *= 0.5f;
+        p = p * 2.0f;
+    }
+    return fabsf(accum);
+}
+
 // Texture::value (src/textures.rs:59-103, src/textures/image.rs:31-65). Checkered nests.
-__device__ inline f3 tex_value(const DevScene &sc, int32_t id, float u, float v) {
+__device__ inline f3 tex_value(const DevScene &sc, int32_t id, float u, float v, f3 p) {
     for (;;) {
         const pts_texture t = sc.textures[id];
         if (t.type == PTS_TEX_SOLID) return mk3(t.color[0], t.color[1], t.color[2]);
+        if (t.type == PTS_TEX_NOISE) {
+            const float k = 1.0f + sinf(t.scale * p.z + 10.0f * noise_turbulence((uint32_t)t.odd, p));
+            return mk3(t.color[0], t.color[1], t.color[2]) * k;
+        }
         if (t.type == PTS_TEX_CHECKERED) {
             long long ui = f2i64_sat(floorf(u * t.scale));
             long long vi = f2i64_sat(floorf(v * t.scale));
@@ -408,7 +457,7 @@ __device__ inline f3 mat_scatter(const DevScene &sc, const DevMaterial &m, Rng &
 template <int MT>
 __device__ inline f3 mat_eval(const DevScene &sc, const DevMaterial &m, f3 w_out, f3 w_in, const Surf &s) {
     if constexpr (MT == PTS_MAT_LAMBERTIAN) {
-        return tex_value(sc, m.texture, s.u, s.v) / PTD_PI;  // lambertian.rs:60-62
+        return tex_value(sc, m.texture, s.u, s.v, s.p) / PTD_PI;  // lambertian.rs:60-62
     } else if constexpr (MT == PTS_MAT_METAL) {
         return mk3(m.p[0], m.p[1], m.p[2]);
     } else if constexpr (MT == PTS_MAT_DIELECTRIC) {
@@ -422,7 +471,7 @@ __device__ inline f3 mat_eval(const DevScene &sc, const DevMaterial &m, f3 w_out
         f3 h = refl ? normalize(w_out + w_in) : normalize(eta * w_out + w_in);
         const bool transmitted = !s.front_face;
         const f3 zero = mk3(0.0f, 0.0f, 0.0f);
-        const f3 base_color = tex_value(sc, m.texture, s.u, s.v);
+        const f3 base_color = tex_value(sc, m.texture, s.u, s.v, s.p);
         f3 f_diffuse = transmitted ? zero : eval_diffuse(roughness, subsurface, base_color, w_out, h, w_in);
         f3 f_sheen = transmitted ? zero : eval_sheen(sheen, sheen_tint, base_color, h, w_in);
         f3 f_metal = zero;
@@ -442,23 +491,23 @@ __device__ inline f3 mat_eval(const DevScene &sc, const DevMaterial &m, f3 w_out
         return diffuse + sheen_c + metal + clearcoat_c + glass;
     } else if constexpr (MT == PTS_MAT_DISNEY_DIFFUSE) {
         f3 h = normalize(w_out + w_in);
-        return eval_diffuse(m.p[0], m.p[1], tex_value(sc, m.texture, s.u, s.v), w_out, h, w_in);
+        return eval_diffuse(m.p[0], m.p[1], tex_value(sc, m.texture, s.u, s.v, s.p), w_out, h, w_in);
     } else if constexpr (MT == PTS_MAT_DISNEY_METAL) {
         if (w_in.y < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
         f3 h = normalize(w_out + w_in);
-        return eval_metal(mat_alpha(m), tex_value(sc, m.texture, s.u, s.v), w_out, h, w_in);
+        return eval_metal(mat_alpha(m), tex_value(sc, m.texture, s.u, s.v, s.p), w_out, h, w_in);
     } else if constexpr (MT == PTS_MAT_DISNEY_GLASS) {
         float eta = s.front_face ? 1.0f / m.p[2] : m.p[2];
         bool refl = w_out.y * w_in.y > 0.0f;
         f3 h = refl ? normalize(w_out + w_in) : normalize(eta * w_out + w_in);
         if (h.y < 0.0f) h = -h;
-        return eval_glass(mat_alpha(m), m.p[2], tex_value(sc, m.texture, s.u, s.v), s.front_face, w_out, h, w_in);
+        return eval_glass(mat_alpha(m), m.p[2], tex_value(sc, m.texture, s.u, s.v, s.p), s.front_face, w_out, h, w_in);
     } else if constexpr (MT == PTS_MAT_DISNEY_CLEARCOAT) {
         f3 h = normalize(w_out + w_in);
         return eval_clearcoat(m.p[0], m.derived[4], m.derived[5], w_out, h, w_in);
     } else if constexpr (MT == PTS_MAT_DISNEY_SHEEN) {
         f3 h = normalize(w_out + w_in);
-        return eval_sheen(m.p[0], m.p[1], tex_value(sc, m.texture, s.u, s.v), h, w_in);
+        return eval_sheen(m.p[0], m.p[1], tex_value(sc, m.texture, s.u, s.v, s.p), h, w_in);
     } else {
         return mk3(0.0f, 0.0f, 0.0f);
     }

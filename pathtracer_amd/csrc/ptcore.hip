@@ -387,7 +387,7 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
     if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
         // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
         f3 e = mk3(0.0f, 0.0f, 0.0f);
-        if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v);
+        if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v, s.p);
         if constexpr (NEE) {
             float w = 1.0f;
             if (b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true>(sc, ro, rd));
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene s
             const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
             const Surf s = make_surf(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), r.t_max, h.u, h.v, h.prim, h.code);
             if (!s.front_face) return;
-            const f3 e = tex_value(sc, sc.mats[mat].texture, s.u, s.v);
+            const f3 e = tex_value(sc, sc.mats[mat].texture, s.u, s.v, s.p);
             const float4 f = ps.shadow_c[slot], c = ps.contrib[slot];
             const f3 add = cmul(mk3(f.x, f.y, f.z), e);
             ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
@@ -1320,7 +1320,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         return fail(ctx, PT_ERR_INVALID, "material index out of range");
     for (uint32_t i = 0; i < s->n_textures; i++) {
         const pts_texture &t = s->textures[i];
-        if (t.type > PTS_TEX_IMAGE) return fail(ctx, PT_ERR_INVALID, "texture %u: unknown type", i);
+        if (t.type > PTS_TEX_NOISE) return fail(ctx, PT_ERR_INVALID, "texture %u: unknown type", i);
         if (t.type == PTS_TEX_CHECKERED) {
             // children must come earlier in the table: rules out cycles
             if (t.odd < 0 || t.even < 0 || t.odd >= (int32_t)i || t.even >= (int32_t)i)

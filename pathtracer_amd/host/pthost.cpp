@@ -180,6 +180,16 @@ TextureRef make(std::shared_ptr<const RgbImage> image) {
     return t;
 }
 }  // namespace Image
+namespace Noise {
+TextureRef make(Color color, float scale, uint32_t seed) {
+    auto t = std::make_shared<Texture>();
+    t->type = PTS_TEX_NOISE;
+    t->albedo = color;
+    t->inv_scale = scale;
+    t->seed = seed;
+    return t;
+}
+}  // namespace Noise
 
 static std::shared_ptr<Material> new_mat(uint32_t type, TextureRef tex) {
     auto m = std::make_shared<Material>();
@@ -550,6 +560,10 @@ int FlatScene::texture_index(const TextureRef &t) {
     d.odd = d.even = d.image = -1;
     if (t->type == PTS_TEX_SOLID) {
         d.color[0] = t->albedo.x; d.color[1] = t->albedo.y; d.color[2] = t->albedo.z;
+    } else if (t->type == PTS_TEX_NOISE) {
+        d.color[0] = t->albedo.x; d.color[1] = t->albedo.y; d.color[2] = t->albedo.z;
+        d.scale = t->inv_scale;
+        d.odd = (int32_t)t->seed;
     } else if (t->type == PTS_TEX_CHECKERED) {
         d.odd = texture_index(t->odd);  // children first: their indices precede the parent's
         d.even = texture_index(t->even);
@@ -768,6 +782,7 @@ struct SrcLoader {
                     if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= i || (uint32_t)t.even >= i) throw std::runtime_error("checker children must precede it");
                     tex[i] = Checkered::make(tex[t.odd], tex[t.even], t.scale);
                     break;
+                case PTS_TEX_NOISE: tex[i] = Noise::make(Color(t.color[0], t.color[1], t.color[2]), t.scale, (uint32_t)t.odd); break;
                 case PTS_TEX_IMAGE:
                     if (t.image >= (int32_t)img.size()) throw std::runtime_error("image index out of range");
                     tex[i] = Image::make(t.image >= 0 ? img[t.image] : nullptr);

@@ -90,6 +90,7 @@ struct Texture {
     TextureRef odd, even;
     float inv_scale = 0;
     std::shared_ptr<const RgbImage> image;  // null = Image::load failed
+    uint32_t seed = 0;                      // Noise
 };
 namespace Solid { TextureRef make(Color albedo); }
 namespace Checkered {
@@ -97,6 +98,8 @@ TextureRef make(TextureRef odd, TextureRef even, float inv_scale);
 TextureRef new_solid(Color odd, Color even, float inv_scale);
 }
 namespace Image { TextureRef make(std::shared_ptr<const RgbImage> image); }
+// Not in the reference: marble-like noise, PTS_TEX_NOISE of ptscene_src.h.
+namespace Noise { TextureRef make(Color color, float scale, uint32_t seed); }
 
 // ---- materials (src/materials/*.rs) ------------------------------------------------------
 struct Material {

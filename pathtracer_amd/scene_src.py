@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 # ---- enums (keep in step with ptscene_src.h) -------------------------------
-TEX_SOLID, TEX_CHECKERED, TEX_IMAGE = 0, 1, 2
+TEX_SOLID, TEX_CHECKERED, TEX_IMAGE, TEX_NOISE = 0, 1, 2, 3
 (MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_DISNEY, MAT_DISNEY_DIFFUSE,
  MAT_DISNEY_METAL, MAT_DISNEY_GLASS, MAT_DISNEY_CLEARCOAT, MAT_DISNEY_SHEEN) = range(10)
 (OP_ROTATE, OP_ROTATE_X, OP_ROTATE_Y, OP_ROTATE_Z, OP_TRANSLATE, OP_TRANSLATE_X, OP_TRANSLATE_Y,
@@ -231,6 +231,11 @@ class SceneSource:
     def checkered(self, odd: int, even: int, scale: float) -> int:
         """``Checkered::new(odd, even, inv_scale)`` — argument order as in the reference."""
         self.textures.append((TEX_CHECKERED, (0.0, 0.0, 0.0), int(odd), int(even), float(scale), -1))
+        return len(self.textures) - 1
+
+    def noise(self, color, scale: float, seed: int = 1) -> int:
+        """Marble-like gradient noise (not in the reference): ``color * (1 + sin(scale * p.z + 10 * turbulence(p)))``."""
+        self.textures.append((TEX_NOISE, tuple(float(c) for c in color), int(seed), -1, float(scale), -1))
         return len(self.textures) - 1
 
     def image(self, rgb8: Optional[np.ndarray]) -> int:

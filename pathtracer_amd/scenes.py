@@ -315,10 +315,11 @@ def interior(width: int = 1920, spp: int = 1024, max_depth: int = 16, seed: int 
 
 
 # --------------------------------------------------------------------------- C2
-def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed: int = 1) -> SceneSource:
+def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed: int = 1, extensions: bool = False) -> SceneSource:
     """The primitives-only part of the "Next Week" final scene: a floor of boxes (instances), an emissive
     quad, glass / metal / textured spheres and a rotated, translated cluster of ~1000 small spheres.
-    Volumes, Perlin noise and motion blur do not exist in the reference and are not part of this scene."""
+    Volumes, Perlin noise and motion blur do not exist in the reference; ``extensions`` adds the ones this
+    build has of its own (the marble sphere's noise texture)."""
     s = SceneSource()
     s.name = "next_week_like"
     ground = s.lambertian((0.48, 0.83, 0.53))
@@ -329,6 +330,7 @@ def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed:
     orange = s.lambertian((0.7, 0.3, 0.1))
     earth = s.lambertian_texture(s.image(None))
     checker = s.lambertian_texture(s.checkered(s.solid((0.9, 0.9, 0.9)), s.solid((0.2, 0.3, 0.1)), 16.0))
+    marble = s.lambertian_texture(s.noise((0.5, 0.5, 0.5), 0.2, seed)) if extensions else checker
     o = s.objects
     boxes_per_side = 20
     h = _hash01(np.arange(boxes_per_side * boxes_per_side, dtype=np.int64), seed)
@@ -347,7 +349,7 @@ def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed:
     o.add_sphere((0.0, 150.0, 145.0), 50.0, metal)
     o.add_sphere((360.0, 150.0, 145.0), 70.0, glass)
     o.add_sphere((400.0, 200.0, 400.0), 100.0, earth)
-    o.add_sphere((220.0, 280.0, 300.0), 80.0, checker)
+    o.add_sphere((220.0, 280.0, 300.0), 80.0, marble)
     cluster = PrimSet()
     r = _hash01(np.arange(3000, dtype=np.int64) + 77777, seed).reshape(1000, 3) * 165.0
     for k in range(1000):

@@ -1,0 +1,56 @@
+"""The noise texture (PTS_TEX_NOISE) is not in the reference; the oracle states it, the device library restates it.
+CPU part: known answers of the oracle's statement.  GPU part: the device against the oracle."""
+import numpy as np
+import pytest
+
+from pathtracer_amd import scenes
+from pathtracer_amd.scene_src import CameraSrc, SceneSource
+
+
+def _scene(width=32, spp=16):
+    s = SceneSource()
+    s.name = "marble"
+    marble = s.lambertian_texture(s.noise((0.5, 0.5, 0.5), 0.2, 7))
+    veined = s.lambertian_texture(s.checkered(s.noise((0.8, 0.3, 0.2), 1.5, 3), s.solid((0.2, 0.2, 0.2)), 4.0))
+    emit = s.diffuse_light_texture(s.noise((2.0, 2.0, 1.5), 0.7, 11))
+    o = s.objects
+    o.add_quad((-20, 0, -20), (40, 0, 0), (0, 0, 40), veined)
+    o.add_sphere((0.0, 2.0, 0.0), 2.0, marble)
+    o.add_sphere((4.5, 1.0, 1.0), 1.0, marble)
+    o.add_quad((-3, 8, -3), (6, 0, 0), (0, 0, 6), emit)
+    s.lights.add_quad((-3, 8, -3), (6, 0, 0), (0, 0, 6), emit)
+    o.build_bvh = True
+    s.camera = CameraSrc(1.0, width, 40.0, (0.0, 5.0, -14.0), (0.0, 2.0, 0.0), 10.0, 0.0, spp, 8, (0.3, 0.35, 0.5))
+    return s
+
+
+def test_value_at_lattice_points_is_closed_form_and_bounded_elsewhere():
+    from oracle.pyoracle import OracleScene
+    o = OracleScene(_scene())
+    w = np.array([0.0, 1.0, 0.0], np.float32)
+    marble = 0  # first material
+    # every octave's noise vanishes on the integer lattice, so the value there is color * (1 + sin(scale * z)), over pi
+    for p in [(0, 0, 0), (3, -2, 5), (-7, 4, -9), (100, 50, -31)]:
+        f, _, _ = o.material_eval(marble, w, w, p=p)
+        want = 0.5 * (1.0 + np.sin(np.float32(0.2) * np.float32(p[2]))) / np.pi
+        assert np.allclose(f, want, rtol=2e-6, atol=1e-7), (p, f, want)
+    rng = np.random.default_rng(3)
+    vals = np.array([o.material_eval(marble, w, w, p=tuple(rng.uniform(-40, 40, 3)))[0] for _ in range(400)])
+    assert np.all(vals >= 0.0) and np.all(vals <= 1.0 / np.pi + 1e-6)
+    assert vals.std() > 0.03  # it is not flat
+    a = o.material_eval(marble, w, w, p=(1.25, 2.5, -3.75))[0]
+    b = o.material_eval(marble, w, w, p=(1.25, 2.5, -3.75))[0]
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_device_restatement_against_the_oracle_per_sample():
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import HostScene, Renderer
+    for src in (_scene(40, 16), scenes.next_week_like(40, 16, max_depth=12, extensions=True)):
+        o, r = OracleScene(src), Renderer(HostScene(src))
+        ref = np.nan_to_num(o.render(0, 4, seed=5, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+        got = np.nan_to_num(r.render_samples(0, 4, seed=5), nan=0.0, posinf=0.0, neginf=0.0)
+        close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+        assert close.mean() > 0.99, (src.name, close.mean())
+        assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
