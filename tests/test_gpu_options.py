@@ -153,3 +153,24 @@ def test_rolling_schedule_survives_setting_changes_between_calls():
         r.render(9, 20, seed=2)
         accs.append(r.read_accum()[0])
     assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
+
+
+def test_deep_paths_fall_back_to_one_batch_at_a_time():
+    # more than 256 bounces: the rolling schedule (one region of path state per bounce) steps aside; same sums
+    from pathtracer_amd.core import PT_OPT_ROLLING
+    src = scenes.cornell(32, 16, max_depth=300)
+    accs = []
+    for rolling in (1 << 20, 0):
+        r = _renderer(src)
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.render(0, 9, seed=4)
+        accs.append(r.read_accum()[0])
+    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
+
+
+def test_new_option_ranges_are_checked():
+    from pathtracer_amd.core import PT_OPT_DEVICE_BVH, PT_OPT_INTEGRATOR, PT_OPT_ROLLING, PT_OPT_TAIL_BELOW, PtError
+    r = _renderer(cornell_small())
+    for key, bad in ((PT_OPT_ROLLING, -1), (PT_OPT_TAIL_BELOW, -1), (PT_OPT_INTEGRATOR, 2), (PT_OPT_INTEGRATOR, 0.5), (PT_OPT_DEVICE_BVH, -3)):
+        with pytest.raises(PtError):
+            r.set_option(key, bad)
