@@ -111,6 +111,8 @@ typedef struct pt_scene_desc {
     const pts_image *images;
     uint64_t n_texel_bytes;
     const uint8_t *texels;
+    uint32_t n_media; /* participating media, not in the reference: see pts_medium; at most PTS_MAX_MEDIA */
+    const pts_medium *media;
 } pt_scene_desc;
 
 /* The fields of Camera that render/get_ray/ray_color read (src/camera.rs:34-61). */

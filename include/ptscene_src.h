@@ -129,6 +129,21 @@ typedef struct pts_camera {
     float background[3];
 } pts_camera;
 
+/* ---- participating media (not in the reference) --------------------------- */
+/* A homogeneous medium filling a sphere, the "constant medium" of the Next Week scene.  A ray that
+   crosses the sphere between its t_min and its closest surface hit scatters after a free flight of
+   -ln(u) / density (u uniform in [0,1)) if that is shorter than its way through the sphere; the path
+   continues from there in a uniformly drawn direction with its throughput multiplied by the albedo
+   texture's value at that point.  Media are tried in index order, each against the closest event so
+   far.  Media are not primitives: they are in no BVH and never appear in hit records. */
+typedef struct pts_medium {
+    float center[3];
+    float radius;
+    float density;
+    int32_t texture; /* albedo */
+} pts_medium;
+enum { PTS_MAX_MEDIA = 8 };
+
 /* ---- the scene ----------------------------------------------------------- */
 enum { PTS_TRI_HAS_NORMALS = 1, PTS_TRI_HAS_UVS = 2 };
 
@@ -168,6 +183,9 @@ typedef struct pts_scene {
        sets[2..] = children of instances. */
     uint32_t n_sets;
     const pts_primset *sets;
+
+    uint32_t n_media; /* at most PTS_MAX_MEDIA */
+    const pts_medium *media;
 } pts_scene;
 
 #ifdef __cplusplus

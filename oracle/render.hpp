@@ -102,6 +102,47 @@ struct Scene {
     Camera camera;
     float bsdf_sample_probability = 1.0f;  // BSDF_SAMPLE_PROBABILITY, src/camera.rs:317
     std::string error;
+    std::vector<pts_medium> media;  // not in the reference, see pts_medium
+
+    // Does the ray scatter in a medium before `t_closest` (its closest surface hit, or infinity)?  Media are
+    // tried in index order, each against the closest event so far; a medium the ray crosses costs one draw.
+    bool medium_event(Rng &rng, const Ray &ray, float t_closest, float &t_event, int &which) const {
+        bool any = false;
+        float best = t_closest;
+        for (size_t m = 0; m < media.size(); m++) {
+            const pts_medium &md = media[m];
+            V3 oc = v3(md.center[0], md.center[1], md.center[2]) - ray.origin;
+            float a = norm_squared(ray.direction);
+            float h = dot(ray.direction, oc);
+            float c = norm_squared(oc) - md.radius * md.radius;
+            float disc = h * h - a * c;
+            if (!(disc >= 0.0f)) continue;
+            float sq = std::sqrt(disc);
+            float t1 = (h - sq) / a, t2 = (h + sq) / a;
+            if (t1 < ray.t_min) t1 = ray.t_min;
+            if (t2 > best) t2 = best;
+            if (!(t1 < t2)) continue;
+            float len = std::sqrt(a);
+            float inside = (t2 - t1) * len;
+            float u = rng.range(0.0f, 1.0f);
+            float dist = (-1.0f / md.density) * std::log(u);
+            if (!(dist <= inside)) continue;
+            best = t1 + dist / len;
+            which = (int)m;
+            any = true;
+        }
+        t_event = best;
+        return any;
+    }
+    // The ray that leaves a scattering event in medium `which` at p: uniform on the sphere, two draws.
+    Ray medium_scatter(Rng &rng, int which, V3 p, Color &albedo) const {
+        albedo = textures.value(media[(size_t)which].texture, 0.0f, 0.0f, p);
+        float u1 = rng.range(0.0f, 1.0f), u2 = rng.range(0.0f, 1.0f);
+        float z = 1.0f - 2.0f * u1;
+        float r = std::sqrt(rmax(0.0f, 1.0f - z * z));
+        float phi = 2.0f * PI_F * u2;
+        return Ray::make(p, v3(r * std::cos(phi), r * std::sin(phi), z));
+    }
 
     const Material *mat(int32_t id) const { return (id >= 0 && (size_t)id < materials.size()) ? &materials[(size_t)id] : nullptr; }
 
@@ -121,6 +162,15 @@ struct Scene {
                 g_ctr->depth_rays[bounce]++;
                 g_ctr->depth_nodes[bounce] += n;
                 if (n > g_ctr->depth_max_nodes[bounce]) g_ctr->depth_max_nodes[bounce] = n;
+            }
+        }
+        if (!media.empty()) {
+            float t_event;
+            int which = 0;
+            if (medium_event(rng, ray_out, any_hit ? rec.t : INFINITY, t_event, which)) {
+                Color albedo;
+                Ray ray_in = medium_scatter(rng, which, ray_out.at(t_event), albedo);
+                return cmul(albedo, ray_color(rng, ray_in, max_depth - 1, rays));
             }
         }
         if (!any_hit) return camera.background;
@@ -175,7 +225,20 @@ struct Scene {
             if (depth == 0) return cmul(beta, gray(0.0f));
             if (rays) (*rays)++;
             HitRecord rec;
-            if (!objects.hit(ray, rec)) return cmul(beta, camera.background);
+            const bool any_hit = objects.hit(ray, rec);
+            if (!media.empty()) {
+                float t_event;
+                int which = 0;
+                if (medium_event(rng, ray, any_hit ? rec.t : INFINITY, t_event, which)) {
+                    Color albedo;
+                    Ray next = medium_scatter(rng, which, ray.at(t_event), albedo);
+                    beta = cmul(beta, albedo);
+                    ray = next;
+                    depth -= 1;
+                    continue;
+                }
+            }
+            if (!any_hit) return cmul(beta, camera.background);
             const Material *material = mat(rec.material);
             if (!material) return cmul(beta, gray(0.0f));
             if (material->is_emissive()) return cmul(beta, shading.emitted(*material, rec));
@@ -391,6 +454,8 @@ inline Scene *load_scene(const pts_scene &s, const pts_camera &cam, std::string 
     if (s.n_sets < 2) { err = "need at least the object set and the light set"; delete sc; return nullptr; }
     load_primset(s, 0, sc->objects, err);
     load_primset(s, 1, sc->lights.objects, err);
+    if (s.n_media > PTS_MAX_MEDIA) err = "too many participating media";
+    else sc->media.assign(s.media, s.media + s.n_media);
     if (!err.empty()) { delete sc; return nullptr; }
     return sc;
 }

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from .scene_src import SceneSource, pts_image, pts_texture
+from .scene_src import SceneSource, pts_image, pts_medium, pts_texture
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _core: Optional[C.CDLL] = None
@@ -60,6 +60,7 @@ class pt_scene_desc(C.Structure):
         ("n_textures", C.c_uint32), ("textures", C.POINTER(pts_texture)),
         ("n_images", C.c_uint32), ("images", C.POINTER(pts_image)),
         ("n_texel_bytes", C.c_uint64), ("texels", C.POINTER(C.c_uint8)),
+        ("n_media", C.c_uint32), ("media", C.POINTER(pts_medium)),
     ]
 
 

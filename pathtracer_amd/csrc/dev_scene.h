@@ -59,12 +59,15 @@ struct DevScene {
     const pts_texture *textures;
     const pts_image *images;
     const uint8_t *texels;
+    const pts_medium *media;    // participating media (pts_medium), n_media of them
     const uint32_t *tri_order;  // [n_tris] position at upload of the triangle now at each position
     DevSet world;   // sets[0]
     DevSet lights;  // sets[1]
     uint32_t n_materials;
     uint32_t n_light_total;  // lights.len() including instances
     uint32_t boxes_finite;   // every coordinate of every BVH box is a finite number
+    uint32_t n_media;
+    uint32_t medium_queue;   // with media: the shade queue that rays without a surface to shade go to
     uint32_t n_wide, n_tris, n_spheres, n_quads, n_insts, n_sets;  // array lengths (bounds-checking build)
 };
 
@@ -81,7 +84,10 @@ struct DevCamera {
 // hit2 encoding: bits 0..1 primitive type, bits 2..31 instance index + 1 (0 = not in an instance)
 #define PTD_HIT_MISS 0xFFFFFFFFu
 
-constexpr int MAX_QUEUES = PTS_MAT_COUNT;
+// One shade queue per material type, and one more for rays that end without a surface to shade
+// when the scene has participating media (they may still scatter on their way out).
+constexpr int PTD_MAT_MEDIUM = PTS_MAT_COUNT;
+constexpr int MAX_QUEUES = PTS_MAT_COUNT + 1;
 
 // Work queues of path slots, in chunks of QUEUE_CHUNK entries.  A producing wave owns one
 // open chunk per queue it writes and appends to it without synchronisation; it takes a new

@@ -538,6 +538,47 @@ __device__ inline float mat_pdf(const DevMaterial &m, f3 w_out, f3 w_in, const S
     }
 }
 
+// ---------------------------------------------------------------- participating media (pts_medium; not in the reference)
+// Does the ray scatter in a medium before t_closest (its closest surface hit, or infinity)?  Media
+// are tried in index order, each against the closest event so far; a medium the ray crosses costs
+// one draw.
+__device__ inline bool medium_event(const DevScene &sc, Rng &rng, f3 o, f3 d, float t_closest, float &t_event, uint32_t &which) {
+    bool any = false;
+    float best = t_closest;
+    for (uint32_t m = 0; m < sc.n_media; m++) {
+        const pts_medium md = sc.media[m];
+        const f3 oc = mk3(md.center[0], md.center[1], md.center[2]) - o;
+        const float a = norm_squared(d);
+        const float h = dot(d, oc);
+        const float c = norm_squared(oc) - md.radius * md.radius;
+        const float disc = h * h - a * c;
+        if (!(disc >= 0.0f)) continue;
+        const float sq = sqrtf(disc);
+        float t1 = (h - sq) / a, t2 = (h + sq) / a;
+        if (t1 < 0.001f) t1 = 0.001f;
+        if (t2 > best) t2 = best;
+        if (!(t1 < t2)) continue;
+        const float len = sqrtf(a);
+        const float inside = (t2 - t1) * len;
+        const float u = rng.range(0.0f, 1.0f);
+        const float dist = (-1.0f / md.density) * logf(u);
+        if (!(dist <= inside)) continue;
+        best = t1 + dist / len;
+        which = m;
+        any = true;
+    }
+    t_event = best;
+    return any;
+}
+// Direction of the ray that leaves a scattering event: uniform on the sphere, two draws.
+__device__ inline f3 medium_direction(Rng &rng) {
+    const float u1 = rng.range(0.0f, 1.0f), u2 = rng.range(0.0f, 1.0f);
+    const float z = 1.0f - 2.0f * u1;
+    const float r = sqrtf(rmax(0.0f, 1.0f - z * z));
+    const float phi = 2.0f * PTD_PI * u2;
+    return mk3(r * cosf(phi), r * sinf(phi), z);
+}
+
 // ---------------------------------------------------------------- lights (src/objects.rs:235-278)
 // pdf of one light for a ray: the primitive's `hit` on a copy of the ray, then its formula.
 // Triangle::pdf of the reference is 1 / area, a density over the triangle rather than over

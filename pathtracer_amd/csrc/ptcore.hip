@@ -48,6 +48,7 @@ struct BatchParams {
     uint32_t npix;
     uint32_t n_slots;        // npix * n_strata
     float bsdf_prob;
+    f3 background;
 };
 // Paths of a batch are numbered pixel-major: slot = pixel * n_strata + (stratum - stratum_first).
 // The 64 lanes of a wave then hold the strata of a few neighbouring pixels — almost the same
@@ -180,15 +181,18 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
             const uint32_t type = code & 3u;
             mat = (type == PT_PRIM_TRI) ? sc.tri_mat[prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[prim] : sc.quad_mat[prim]);
         }
-        if (mat >= 0) {
-            qslot = sc.mat_queue[mat];
-        } else if (!ps.nee) {
-            const float4 b = ps.beta[slot];
-            const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
-            ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
-        } else if (code == PTD_HIT_MISS) {  // contrib already holds the light samples of the earlier vertices
-            const float4 b = ps.beta[slot], c = ps.contrib[slot];
-            ps.contrib[slot] = make_float4(c.x + b.x * background.x, c.y + b.y * background.y, c.z + b.z * background.z, 0.0f);
+        // without a surface to shade the path ends here, unless the scene has participating media: then it
+        // may still scatter on its way out, and shade_vertex<PTD_MAT_MEDIUM> decides (medium_queue is 0xFF otherwise)
+        qslot = mat >= 0 ? sc.mat_queue[mat] : sc.medium_queue;
+        if (qslot == 0xFFu) {
+            if (!ps.nee) {
+                const float4 b = ps.beta[slot];
+                const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
+                ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+            } else if (code == PTD_HIT_MISS) {  // contrib already holds the light samples of the earlier vertices
+                const float4 b = ps.beta[slot], c = ps.contrib[slot];
+                ps.contrib[slot] = make_float4(c.x + b.x * background.x, c.y + b.y * background.y, c.z + b.z * background.z, 0.0f);
+            }
         }
     }
     // one pass per material queue that some lane of this wave needs
@@ -356,31 +360,10 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
     flush_counters(COUNT, tc, stats);
 }
 
-// One path vertex: the body of Camera::ray_color after the hit (src/camera.rs:286-369), in
-// multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
-// type MT; `local` is its number within its batch.  Returns true when the path goes on: its
-// next ray is then in ps.ray_o / ps.ray_d.
-//
-// NEE selects the integrator that is not in the reference (PT_OPT_INTEGRATOR = 1): next-event
-// estimation with one light sample per vertex and the balance heuristic, at the vertices whose
-// material has a scattering_pdf that is the density of its scatter (Lambertian, DisneyDiffuse,
-// DisneySheen: checked numerically in tests/test_material_pdfs.py; for the other Disney lobes of
-// the reference it is not, so no combination of the two samplers can reproduce what the
-// reference's estimator converges to, and those vertices are handled exactly as the reference
-// does, with BSDF sampling alone).  At a vertex with light sampling a direction is drawn with
-// LightBuffer::sample; when its density lp is positive and finite and the BSDF sampler could
-// have produced it (sp > 0), shadow = true and the path leaves (direction, beta * f * |cos| /
-// (lp + sp)) in ps.hit / ps.shadow_c for the shadow-ray kernel.  The path itself continues by
-// BSDF sampling with the reference's roulette; an emitter found that way counts with weight
-// sp' / (sp' + lp'), and fully after the camera or a vertex without light sampling.  Radiance is
-// added to ps.contrib as it is found; paths that end without finding any add nothing.
+// The surface part of shade_vertex below.
 template <int MT, bool NEE>
-__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow) {
-    const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
-    const uint32_t code = ps.hit2[slot];
-    const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
-    f3 beta = mk3(b4.x, b4.y, b4.z);
-    uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
+__device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow,
+                                              f3 ro, f3 rd, float4 h4, float4 b4, uint32_t code, f3 beta, uint32_t depth, uint32_t rng_counter) {
     const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code);
     const DevMaterial m = sc.mats[s.material];
     shadow = false;
@@ -401,7 +384,7 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
         uint32_t pixel, stratum;
         slot_to_sample(bp, local, pixel, stratum);
         Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, __float_as_uint(ro4.w));
+        rng.init(bp.seed_mixed, pixel, stratum, rng_counter);
         const Onb surface = make_onb(s.normal);
         const f3 w_out = -normalize(to_local(surface, rd));
         f3 w_in_world;
@@ -487,11 +470,76 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
     return false;
 }
 
+// One path vertex: the body of Camera::ray_color after the hit (src/camera.rs:286-369), in
+// multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
+// type MT; `local` is its number within its batch.  Returns true when the path goes on: its
+// next ray is then in ps.ray_o / ps.ray_d.
+//
+// NEE selects the integrator that is not in the reference (PT_OPT_INTEGRATOR = 1): next-event
+// estimation with one light sample per vertex and the balance heuristic, at the vertices whose
+// material has a scattering_pdf that is the density of its scatter (Lambertian, DisneyDiffuse,
+// DisneySheen: checked numerically in tests/test_material_pdfs.py; for the other Disney lobes of
+// the reference it is not, so no combination of the two samplers can reproduce what the
+// reference's estimator converges to, and those vertices are handled exactly as the reference
+// does, with BSDF sampling alone).  At a vertex with light sampling a direction is drawn with
+// LightBuffer::sample; when its density lp is positive and finite and the BSDF sampler could
+// have produced it (sp > 0), shadow = true and the path leaves (direction, beta * f * |cos| /
+// (lp + sp)) in ps.hit / ps.shadow_c for the shadow-ray kernel.  The path itself continues by
+// BSDF sampling with the reference's roulette; an emitter found that way counts with weight
+// sp' / (sp' + lp'), and fully after the camera or a vertex without light sampling.  Radiance is
+// added to ps.contrib as it is found; paths that end without finding any add nothing.
+template <int MT, bool NEE, bool MEDIA = false>
+__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow) {
+    const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
+    const uint32_t code = ps.hit2[slot];
+    const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
+    f3 beta = mk3(b4.x, b4.y, b4.z);
+    uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
+    shadow = false;
+    uint32_t rng_counter = __float_as_uint(ro4.w);
+    if constexpr (MT == PTD_MAT_MEDIUM || MEDIA) {
+        // participating media (not in the reference): the ray may scatter before it reaches what it hit
+        uint32_t pixel, stratum;
+        slot_to_sample(bp, local, pixel, stratum);
+        Rng rng;
+        rng.init(bp.seed_mixed, pixel, stratum, rng_counter);
+        const bool missed = MT == PTD_MAT_MEDIUM && code == PTD_HIT_MISS;
+        float t_event;
+        uint32_t which = 0u;
+        if (medium_event(sc, rng, ro, rd, missed ? INFINITY : h4.x, t_event, which)) {
+            const f3 p = ro + t_event * rd;
+            const f3 albedo = tex_value(sc, sc.media[which].texture, 0.0f, 0.0f, p);
+            const f3 dir = medium_direction(rng);
+            beta = cmul(beta, albedo);
+            depth -= 1u;
+            if (depth == 0u) {
+                ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
+                return false;
+            }
+            ps.ray_o[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.counter));
+            ps.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth));
+            ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+            return true;
+        }
+        rng_counter = rng.counter;
+        if constexpr (MT == PTD_MAT_MEDIUM) {  // nothing to shade: src/camera.rs:371, :277-283
+            const f3 l = missed ? bp.background : mk3(0.0f, 0.0f, 0.0f);
+            ps.contrib[slot] = make_float4(beta.x * l.x, beta.y * l.y, beta.z * l.z, 0.0f);
+            return false;
+        }
+    }
+    if constexpr (MT == PTD_MAT_MEDIUM) return false;
+    else return shade_surface<MT, NEE>(sc, ps, bp, slot, local, shadow, ro, rd, h4, b4, code, beta, depth, rng_counter);
+}
+
 // shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
 // ROLL: the queue mixes batches, `bp` holds what they have in common and the rest comes from the
 // path's region.
-template <int MT, bool ROLL, bool NEE>
+// MODE: 0 = the reference's estimator, 1 = next-event estimation, 2 = the reference's estimator in a scene with
+// participating media.
+template <int MT, bool ROLL, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
+    constexpr bool NEE = MODE == 1, MEDIA = MODE == 2;
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
@@ -512,9 +560,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
                 mine.seed_mixed = rp.seed_mixed;
                 mine.stratum_first = rp.stratum_first;
                 mine.n_strata = rp.n_strata;
-                alive = shade_vertex<MT, NEE>(sc, ps, mine, slot, slot - region * ps.region_cap, shadow);
+                alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, mine, slot, slot - region * ps.region_cap, shadow);
             } else {
-                alive = shade_vertex<MT, NEE>(sc, ps, bp, slot, slot, shadow);
+                alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, bp, slot, slot, shadow);
             }
         }
         if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
@@ -1338,8 +1386,15 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         const bool needs_tex = !(m.type == PTS_MAT_METAL || m.type == PTS_MAT_DIELECTRIC || m.type == PTS_MAT_DISNEY_CLEARCOAT);
         if (needs_tex && (m.texture < 0 || m.texture >= (int32_t)s->n_textures)) return fail(ctx, PT_ERR_INVALID, "material %u: texture index out of range", i);
     }
+    if (s->n_media > PTS_MAX_MEDIA || (s->n_media && !s->media)) return fail(ctx, PT_ERR_INVALID, "at most %d participating media, in a non-NULL array", (int)PTS_MAX_MEDIA);
+    for (uint32_t i = 0; i < s->n_media; i++) {
+        const pts_medium &m = s->media[i];
+        if (!(m.radius > 0.0f) || !(m.density > 0.0f) || m.texture < 0 || m.texture >= (int32_t)s->n_textures)
+            return fail(ctx, PT_ERR_INVALID, "medium %u: radius and density must be positive and the texture must exist", i);
+    }
     // a shade queue (and a shade kernel per bounce) only for material types some primitive uses
-    bool type_present[PTS_MAT_COUNT] = {false};
+    bool type_present[MAX_QUEUES] = {false};
+    type_present[PTD_MAT_MEDIUM] = s->n_media != 0;
     auto mark = [&](const int32_t *m, uint32_t n) {
         for (uint32_t i = 0; i < n; i++)
             if (m[i] >= 0) type_present[s->materials[m[i]].type] = true;
@@ -1424,8 +1479,8 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     static_assert(sizeof(DevMaterial) == sizeof(pt_material_desc), "material layout");
     if (s->n_materials) std::memcpy(mats.data(), s->materials, (size_t)s->n_materials * sizeof(DevMaterial));
     ctx->n_queues = 0;
-    int slot_of_type[PTS_MAT_COUNT];
-    for (int t = 0; t < PTS_MAT_COUNT; t++) {
+    int slot_of_type[MAX_QUEUES];
+    for (int t = 0; t < MAX_QUEUES; t++) {
         slot_of_type[t] = -1;
         if (type_present[t]) {
             slot_of_type[t] = (int)ctx->n_queues;
@@ -1500,6 +1555,11 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     d.images = pim;
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pu8, s->texels, (size_t)s->n_texel_bytes))) return rc;
     d.texels = pu8;
+    pts_medium *pmed;
+    if ((rc = dev_upload(ctx, ctx->scene_allocs, &pmed, s->media, s->n_media))) return rc;
+    d.media = pmed;
+    d.n_media = s->n_media;
+    d.medium_queue = s->n_media ? (uint32_t)slot_of_type[PTD_MAT_MEDIUM] : 0xFFu;
     d.world = sets[0];
     d.lights = sets[1];
     d.n_materials = s->n_materials;
@@ -1653,9 +1713,11 @@ template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
 #define SHADE(R, N) hipLaunchKernelGGL((k_shade<MT, R, N>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats)
     if (l.ps->nee) {
-        if (l.roll) SHADE(true, true); else SHADE(false, true);
+        if (l.roll) SHADE(true, 1); else SHADE(false, 1);
+    } else if (l.ctx->scene.n_media != 0) {
+        if (l.roll) SHADE(true, 2); else SHADE(false, 2);
     } else {
-        if (l.roll) SHADE(true, false); else SHADE(false, false);
+        if (l.roll) SHADE(true, 0); else SHADE(false, 0);
     }
 #undef SHADE
 }
@@ -1671,6 +1733,7 @@ static void launch_shade_type(int type, const ShadeLaunch &l) {
         case PTS_MAT_DISNEY_GLASS: launch_shade<PTS_MAT_DISNEY_GLASS>(l); break;
         case PTS_MAT_DISNEY_CLEARCOAT: launch_shade<PTS_MAT_DISNEY_CLEARCOAT>(l); break;
         case PTS_MAT_DISNEY_SHEEN: launch_shade<PTS_MAT_DISNEY_SHEEN>(l); break;
+        case PTD_MAT_MEDIUM: launch_shade<PTD_MAT_MEDIUM>(l); break;
     }
 }
 
@@ -1723,7 +1786,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     harvest_set(ctx, pp, (int)(pp.batches & 1u));  // the set this batch is about to record into
     int rc = ensure_paths(ctx, pp, n_slots);
     if (rc) return rc;
-    BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->nee ? 1.0f : ctx->bsdf_prob};
+    BatchParams bp{mix64_host(seed), first, k, npix, (uint32_t)n_slots, ctx->nee ? 1.0f : ctx->bsdf_prob, ctx->cam.background};
     hipStream_t st = pp.stream;
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.bounce_rays, 0, BOUNCE_PROFILE_LEN * sizeof(uint32_t), st));
@@ -1745,7 +1808,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     };
     // From the first bounce expected to carry fewer than tail_below rays, one launch finishes the batch.
     uint32_t tail_from = depth;
-    if (ctx->tail_below > 0 && !ctx->counters && !ctx->nee)
+    if (ctx->tail_below > 0 && !ctx->counters && !ctx->nee && ctx->scene.n_media == 0)
         for (uint32_t b = 1; b < depth; b++) {
             const uint64_t e = expected(b);
             if (e == 0) break;
@@ -1881,6 +1944,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb) {
     BatchParams common{};
     common.npix = ctx->cam.width * ctx->cam.height;
     common.bsdf_prob = ctx->nee ? 1.0f : ctx->bsdf_prob;
+    common.background = ctx->cam.background;
     const int grid_shade = grid_fixed(ctx, bound, ctx->shade_blocks_per_cu);
     for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, true});
     if (ctx->nee) launch_shadow(ctx, st, grid_fixed(ctx, bound), ps, parity);
@@ -1937,6 +2001,7 @@ static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
     if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PT_ERR_STATE, "upload a scene and set a camera before rendering");
     const uint64_t total = (uint64_t)ctx->cam.sqrt_spp * ctx->cam.sqrt_spp;
     if (b > e || e > total) return fail(ctx, PT_ERR_INVALID, "stratum range [%u,%u) outside [0,%llu)", b, e, (unsigned long long)total);
+    if (ctx->nee && ctx->scene.n_media != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation does not handle participating media");
     if (ctx->nee && (ctx->counters || !ctx->use_wide()))
         return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation runs on the ray-drawing traversal only (no test counters, no reference-order traversal)");
     return PT_OK;
@@ -1964,7 +2029,7 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         const uint32_t n_batches = (total + k_tick - 1) / k_tick, per_batch = (total + n_batches - 1) / n_batches;
         for (uint32_t s = stratum_begin; s < stratum_end;) {
             const uint32_t k = std::min(per_batch, stratum_end - s);
-            BatchParams bp{mix64_host(seed), s, k, npix, npix * k, ctx->bsdf_prob};
+            BatchParams bp{mix64_host(seed), s, k, npix, npix * k, ctx->bsdf_prob, ctx->cam.background};
             if ((rc = roll_step(ctx, &bp))) return rc;
             ctx->n_samples += k;
             s += k;

@@ -641,6 +641,16 @@ uint32_t FlatScene::add_set(const PrimitiveBuffer &pb) {
     }
     return index;
 }
+void FlatScene::add_medium(Point3 center, float radius, float density, const TextureRef &albedo) {
+    if (media_.size() >= PTS_MAX_MEDIA) throw std::runtime_error("too many participating media");
+    pts_medium m{};
+    m.center[0] = center.x; m.center[1] = center.y; m.center[2] = center.z;
+    m.radius = radius;
+    m.density = density;
+    m.texture = texture_index(albedo);
+    media_.push_back(m);
+}
+
 void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights) {
     add_set(objects);
     add_set(lights.objects);
@@ -667,6 +677,7 @@ void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights)
     d.n_textures = (uint32_t)textures_.size(); d.textures = textures_.data();
     d.n_images = (uint32_t)images_.size(); d.images = images_.data();
     d.n_texel_bytes = texels_.size(); d.texels = texels_.data();
+    d.n_media = (uint32_t)media_.size(); d.media = media_.data();
     desc_ = d;
 }
 
@@ -902,6 +913,13 @@ pth_scene *pth_scene_build_opts(const pts_scene *scene, const pts_camera *camera
         for (const MaterialRef &m : L.mat) out->flat.material_index(m);
         L.load_set(0, out->objects, 0);
         L.load_set(1, out->lights.objects, 0);
+        if (scene->n_media && !scene->media) throw std::runtime_error("media is NULL");
+        for (uint32_t k = 0; k < scene->n_media; k++) {
+            const pts_medium &m = scene->media[k];
+            if (m.texture < 0 || (size_t)m.texture >= L.tex.size()) throw std::runtime_error("medium: texture index out of range");
+            if (!(m.radius > 0.0f) || !(m.density > 0.0f)) throw std::runtime_error("medium: radius and density must be positive");
+            out->flat.add_medium(Point3(m.center[0], m.center[1], m.center[2]), m.radius, m.density, L.tex[m.texture]);
+        }
         out->flat.build(out->objects, out->lights);
         const pts_camera &c = *camera;
         out->camera = std::make_unique<Camera>(c.aspect_ratio, c.image_width, c.vfov, Point3(c.look_from[0], c.look_from[1], c.look_from[2]),

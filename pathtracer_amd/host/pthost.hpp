@@ -266,6 +266,8 @@ public:
     int texture_index(const TextureRef &t);
     void build(const PrimitiveBuffer &objects, const LightBuffer &lights);
     const pt_scene_desc &desc() const { return desc_; }
+    // Participating media (pts_medium; not in the reference).  Call before build().
+    void add_medium(Point3 center, float radius, float density, const TextureRef &albedo);
 
 private:
     uint32_t add_set(const PrimitiveBuffer &pb);
@@ -280,6 +282,7 @@ private:
     std::vector<pts_texture> textures_;
     std::vector<pts_image> images_;
     std::vector<uint8_t> texels_;
+    std::vector<pts_medium> media_;
     std::unordered_map<const Material *, int> mat_ids_;
     std::unordered_map<const Texture *, int> tex_ids_;
     std::unordered_map<const RgbImage *, int> img_ids_;

@@ -62,6 +62,10 @@ class pts_camera(C.Structure):
                 ("background", C.c_float * 3)]
 
 
+class pts_medium(C.Structure):
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("density", C.c_float), ("texture", C.c_int32)]
+
+
 class pts_scene(C.Structure):
     _fields_ = [
         ("n_textures", C.c_uint32), ("textures", C.POINTER(pts_texture)),
@@ -75,6 +79,7 @@ class pts_scene(C.Structure):
         ("n_instances", C.c_uint32), ("instances", C.POINTER(pts_instance)),
         ("n_ops", C.c_uint32), ("ops", C.POINTER(pts_xform_op)),
         ("n_sets", C.c_uint32), ("sets", C.POINTER(pts_primset)),
+        ("n_media", C.c_uint32), ("media", C.POINTER(pts_medium)),
     ]
 
 
@@ -221,7 +226,12 @@ class SceneSource:
         self.lights = PrimSet()
         self.camera: Optional[CameraSrc] = None
         self.name = ""
+        self.media: List[tuple] = []
         self._keep = None
+
+    def add_medium(self, center, radius: float, density: float, albedo_texture: int):
+        """A homogeneous medium filling a sphere (``pts_medium``; not in the reference)."""
+        self.media.append((tuple(float(c) for c in center), float(radius), float(density), int(albedo_texture)))
 
     # -- textures (src/textures.rs) -------------------------------------------
     def solid(self, color) -> int:
@@ -369,7 +379,11 @@ class SceneSource:
         sc.n_instances = ni; sc.instances = C.cast(cinst, C.POINTER(pts_instance))
         sc.n_ops = len(ops); sc.ops = C.cast(cops, C.POINTER(pts_xform_op))
         sc.n_sets = len(sets); sc.sets = C.cast(csets, C.POINTER(pts_primset))
+        cmed = (pts_medium * max(1, len(self.media)))()
+        for k, (center, radius, density, tex) in enumerate(self.media):
+            cmed[k].center[:] = center; cmed[k].radius = radius; cmed[k].density = density; cmed[k].texture = tex
+        sc.n_media = len(self.media); sc.media = C.cast(cmed, C.POINTER(pts_medium))
         cam = self.camera.to_c()
-        self._keep = (a_tri_pos, a_tri_nrm, a_tri_uv, a_tri_flags, a_tri_mat, a_spheres, a_sphere_mat, a_quads,
+        self._keep = (cmed, a_tri_pos, a_tri_nrm, a_tri_uv, a_tri_flags, a_tri_mat, a_spheres, a_sphere_mat, a_quads,
                       a_quad_mat, ctex, cimg, a_texels, cmat, cinst, cops, csets, sc, cam)
         return sc, cam

@@ -319,7 +319,8 @@ def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed:
     """The primitives-only part of the "Next Week" final scene: a floor of boxes (instances), an emissive
     quad, glass / metal / textured spheres and a rotated, translated cluster of ~1000 small spheres.
     Volumes, Perlin noise and motion blur do not exist in the reference; ``extensions`` adds the ones this
-    build has of its own (the marble sphere's noise texture)."""
+    build has of its own: the marble sphere's noise texture, the blue medium inside the second glass sphere
+    and the thin mist around everything."""
     s = SceneSource()
     s.name = "next_week_like"
     ground = s.lambertian((0.48, 0.83, 0.53))
@@ -358,6 +359,9 @@ def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed:
     ci = InstanceSrc(cluster).rotate_y(_radians_f32(15.0)).translate((-100.0, 270.0, 395.0))
     o.add_instance(ci)
     o.build_bvh = True
+    if extensions:
+        s.add_medium((360.0, 150.0, 145.0), 70.0, 0.2, s.solid((0.2, 0.4, 0.9)))
+        s.add_medium((0.0, 0.0, 0.0), 5000.0, 0.0001, s.solid((1.0, 1.0, 1.0)))
     s.camera = CameraSrc(1.0, width, 40.0, (478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 1.0, 0.0, spp, max_depth,
                          (0.0, 0.0, 0.0))
     return s
