@@ -113,6 +113,9 @@ typedef struct pt_scene_desc {
     const uint8_t *texels;
     uint32_t n_media; /* participating media, not in the reference: see pts_medium; at most PTS_MAX_MEDIA */
     const pts_medium *media;
+    uint32_t n_moving;   /* moving spheres, not in the reference: see pts_moving_sphere.  They are the last n_moving */
+    const float *moving; /* entries of spheres[] (centre at time 0) and sphere_mat[], outside every set;
+                            moving[n][3] = centre at time 1 minus centre at time 0 */
 } pt_scene_desc;
 
 /* The fields of Camera that render/get_ray/ray_color read (src/camera.rs:34-61). */

@@ -144,6 +144,20 @@ typedef struct pts_medium {
 } pts_medium;
 enum { PTS_MAX_MEDIA = 8 };
 
+/* ---- moving spheres (not in the reference) ---------------------------------- */
+/* Motion blur of the Next Week scene: a sphere whose centre moves linearly from center0 at time 0 to
+   center1 at time 1.  Every path has one time in [0,1), a hash of its generator's key that consumes none of
+   its draws, and sees the sphere where it is then: Sphere::hit (src/objects/sphere.rs:56-99) with that centre.
+   Moving spheres are tested after everything else (PrimitiveBuffer::hit, src/objects.rs:191-197), in index
+   order, against the closest hit so far; they are in no set, no BVH and no light list. */
+typedef struct pts_moving_sphere {
+    float center0[3];
+    float center1[3];
+    float radius;
+    int32_t material;
+} pts_moving_sphere;
+enum { PTS_MAX_MOVING = 8 };
+
 /* ---- the scene ----------------------------------------------------------- */
 enum { PTS_TRI_HAS_NORMALS = 1, PTS_TRI_HAS_UVS = 2 };
 
@@ -186,6 +200,9 @@ typedef struct pts_scene {
 
     uint32_t n_media; /* at most PTS_MAX_MEDIA */
     const pts_medium *media;
+
+    uint32_t n_moving; /* at most PTS_MAX_MOVING */
+    const pts_moving_sphere *moving;
 } pts_scene;
 
 #ifdef __cplusplus

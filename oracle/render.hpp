@@ -103,6 +103,26 @@ struct Scene {
     float bsdf_sample_probability = 1.0f;  // BSDF_SAMPLE_PROBABILITY, src/camera.rs:317
     std::string error;
     std::vector<pts_medium> media;  // not in the reference, see pts_medium
+    std::vector<pts_moving_sphere> moving;  // not in the reference, see pts_moving_sphere
+
+    // The time of a path: a hash of its generator's key, none of its draws.
+    static float path_time(const Rng &rng) { return (float)(uint32_t)(mix64(rng.key ^ 0x6D6F74696F6E5F74ull) >> 40) * (1.0f / 16777216.0f); }
+    // PrimitiveBuffer::hit, then the moving spheres where they are at the path's time.
+    bool hit_scene(const Rng &rng, Ray &ray, HitRecord &rec) const {
+        bool any = objects.hit(ray, rec);
+        if (moving.empty()) return any;
+        const float time = path_time(rng);
+        for (const pts_moving_sphere &m : moving) {
+            V3 c0 = v3(m.center0[0], m.center0[1], m.center0[2]), c1 = v3(m.center1[0], m.center1[1], m.center1[2]);
+            Sphere s = Sphere::make(c0 + time * (c1 - c0), m.radius, m.material);
+            HitRecord h;
+            if (s.hit(ray, h)) {
+                rec = h;
+                any = true;
+            }
+        }
+        return any;
+    }
 
     // Does the ray scatter in a medium before `t_closest` (its closest surface hit, or infinity)?  Media are
     // tried in index order, each against the closest event so far; a medium the ray crosses costs one draw.
@@ -154,7 +174,7 @@ struct Scene {
         if (g_ctr) g_ctr->rays++;
         HitRecord rec;
         const uint64_t nodes_before = g_ctr ? g_ctr->nodes : 0;
-        const bool any_hit = objects.hit(ray_out, rec);
+        const bool any_hit = hit_scene(rng, ray_out, rec);
         if (g_ctr) {
             const uint32_t bounce = camera.max_depth >= max_depth ? camera.max_depth - max_depth : 0;
             const uint64_t n = g_ctr->nodes - nodes_before;
@@ -225,7 +245,7 @@ struct Scene {
             if (depth == 0) return cmul(beta, gray(0.0f));
             if (rays) (*rays)++;
             HitRecord rec;
-            const bool any_hit = objects.hit(ray, rec);
+            const bool any_hit = hit_scene(rng, ray, rec);
             if (!media.empty()) {
                 float t_event;
                 int which = 0;
@@ -456,6 +476,8 @@ inline Scene *load_scene(const pts_scene &s, const pts_camera &cam, std::string 
     load_primset(s, 1, sc->lights.objects, err);
     if (s.n_media > PTS_MAX_MEDIA) err = "too many participating media";
     else sc->media.assign(s.media, s.media + s.n_media);
+    if (s.n_moving > PTS_MAX_MOVING) err = "too many moving spheres";
+    else sc->moving.assign(s.moving, s.moving + s.n_moving);
     if (!err.empty()) { delete sc; return nullptr; }
     return sc;
 }

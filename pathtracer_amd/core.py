@@ -61,6 +61,7 @@ class pt_scene_desc(C.Structure):
         ("n_images", C.c_uint32), ("images", C.POINTER(pts_image)),
         ("n_texel_bytes", C.c_uint64), ("texels", C.POINTER(C.c_uint8)),
         ("n_media", C.c_uint32), ("media", C.POINTER(pts_medium)),
+        ("n_moving", C.c_uint32), ("moving", C.POINTER(C.c_float)),
     ]
 
 

@@ -88,6 +88,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+// The time of a path (moving spheres): a hash of its generator's key, none of its draws.
+__device__ __forceinline__ float path_time(uint64_t key) { return (float)(uint32_t)(mix64(key ^ 0x6D6F74696F6E5F74ull) >> 40) * (1.0f / 16777216.0f); }
+
 struct Rng {
     uint64_t key;
     uint32_t counter;

@@ -60,6 +60,8 @@ struct DevScene {
     const pts_image *images;
     const uint8_t *texels;
     const pts_medium *media;    // participating media (pts_medium), n_media of them
+    const float4 *moving_delta; // moving spheres (pts_moving_sphere): centre at time 1 minus centre at time 0, for the
+                                // last n_moving entries of `spheres`, which no set and no BVH refers to
     const uint32_t *tri_order;  // [n_tris] position at upload of the triangle now at each position
     DevSet world;   // sets[0]
     DevSet lights;  // sets[1]
@@ -67,6 +69,7 @@ struct DevScene {
     uint32_t n_light_total;  // lights.len() including instances
     uint32_t boxes_finite;   // every coordinate of every BVH box is a finite number
     uint32_t n_media;
+    uint32_t n_moving, n_static_spheres;
     uint32_t medium_queue;   // with media: the shade queue that rays without a surface to shade go to
     uint32_t n_wide, n_tris, n_spheres, n_quads, n_insts, n_sets;  // array lengths (bounds-checking build)
 };
@@ -146,6 +149,7 @@ struct PathState {
     // ray origin (ray_o) along hit.xyz (hit is free between shading and the next closest-hit step); if it
     // reaches an emitter, shadow_c times the emitted radiance is added to the path's contrib
     uint32_t nee;
+    uint32_t moving;  // the scene has moving spheres: beta.w holds the path's time instead
     uint32_t *shadow_queue;
     float4 *shadow_c;
 };

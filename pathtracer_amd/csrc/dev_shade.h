@@ -107,8 +107,9 @@ __device__ __forceinline__ void sphere_uv(f3 p, float &u, float &v) {
 
 // Rebuilds the HitRecord of the accepted candidate: Triangle::hit (:199-217),
 // Sphere::hit (:82-96), Quad::hit (:137-157), then Instance::hit (:391-397).
+// `time`: the path's time, for the spheres that move (ignored where the scene has none).
 __device__ inline Surf make_surf(const DevScene &sc, f3 ro, f3 rd, float t, float hu, float hv, uint32_t prim,
-                                 uint32_t code) {
+                                 uint32_t code, float time = 0.0f) {
     Surf s;
     const uint32_t type = code & 3u, inst1 = code >> 2;
     Affine fwd;
@@ -136,7 +137,12 @@ __device__ inline Surf make_surf(const DevScene &sc, f3 ro, f3 rd, float t, floa
     } else if (type == PT_PRIM_SPHERE) {
         const float4 sp = sc.spheres[prim];
         f3 at = ro + t * rd;
-        outward = (at - mk3(sp.x, sp.y, sp.z)) / sp.w;
+        f3 center = mk3(sp.x, sp.y, sp.z);
+        if (sc.n_moving != 0u && prim >= sc.n_static_spheres) {
+            const float4 dl = sc.moving_delta[prim - sc.n_static_spheres];
+            center = center + time * mk3(dl.x, dl.y, dl.z);
+        }
+        outward = (at - center) / sp.w;
         s.p = at;
         sphere_uv(outward, s.u, s.v);
         s.material = sc.sphere_mat[prim];

@@ -212,11 +212,15 @@ __device__ __forceinline__ void hit_prim<PT_PRIM_TRI>(const DevScene &sc, uint32
     h.code = PT_PRIM_TRI | inst_code;
 }
 
+// Sphere::hit (src/objects/sphere.rs:56-99) for sphere g with its centre and radius in s.
+__device__ __forceinline__ void hit_sphere(float4 s, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code);
 template <>
 __device__ __forceinline__ void hit_prim<PT_PRIM_SPHERE>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
                                                          uint32_t inst_code, TravCounters &tc) {
     tc.spheres++;
-    const float4 s = sc.spheres[g];
+    hit_sphere(sc.spheres[g], g, r, h, inst_code);
+}
+__device__ __forceinline__ void hit_sphere(float4 s, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code) {
     f3 oc = mk3(s.x, s.y, s.z) - r.o;
     float a = norm_squared(r.d);
     float hh = dot(r.d, oc);

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, B
         const uint32_t slot = base + local;
         ps.ray_o[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.counter));
         ps.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cam.max_depth));
-        ps.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        ps.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, ps.moving ? path_time(rng.key) : 0.0f);
         ps.contrib[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (!ROLL) ps.ray_queue[0][slot] = slot;
     }
@@ -279,7 +279,9 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
 #endif
 // The work is the current ray queue followed by the `n_new` paths in slots new_base.. that a
 // k_raygen<true> has just started (no queue entries exist for those).
-template <bool INSTANCES>
+// MOVING: the scene has moving spheres (pts_moving_sphere): a finished ray is tested against them, where
+// they are at its path's time, before it is classified.
+template <bool INSTANCES, bool MOVING>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, uint32_t new_base,
                                                                       uint32_t n_new, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
@@ -312,11 +314,28 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
             d = mk3(rd.x, rd.y, rd.z);
         },
         [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
-            if (done) {
-                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-                ps.hit2[slot] = h.code;
+            if constexpr (MOVING) {
+                TravRay r2 = r;
+                HitState h2 = h;
+                if (done) {
+                    const float time = ps.beta[slot].w;
+                    for (uint32_t k = 0; k < sc.n_moving; k++) {
+                        const uint32_t g = sc.n_static_spheres + k;
+                        const float4 sp = sc.spheres[g], dl = sc.moving_delta[k];
+                        const f3 c = mk3(sp.x, sp.y, sp.z) + time * mk3(dl.x, dl.y, dl.z);
+                        hit_sphere(make_float4(c.x, c.y, c.z, sp.w), g, r2, h2, 0u);
+                    }
+                    ps.hit[slot] = make_float4(r2.t_max, h2.u, h2.v, __uint_as_float(h2.prim));
+                    ps.hit2[slot] = h2.code;
+                }
+                classify(sc, ps, parity, background, done, slot, h2.code, h2.prim);
+            } else {
+                if (done) {
+                    ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+                    ps.hit2[slot] = h.code;
+                }
+                classify(sc, ps, parity, background, done, slot, h.code, h.prim);
             }
-            classify(sc, ps, parity, background, done, slot, h.code, h.prim);
         });
     shade_push_close(ps);
 }
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
 template <int MT, bool NEE>
 __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow,
                                               f3 ro, f3 rd, float4 h4, float4 b4, uint32_t code, f3 beta, uint32_t depth, uint32_t rng_counter) {
-    const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code);
+    const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code, NEE ? 0.0f : b4.w);
     const DevMaterial m = sc.mats[s.material];
     shadow = false;
     if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
@@ -461,7 +480,7 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
             } else {
                 ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
                 ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
-                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, drawn_with);
+                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, NEE ? drawn_with : b4.w);  // w: the path's time unless NEE
                 return true;
             }
         }
@@ -518,7 +537,7 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
             }
             ps.ray_o[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.counter));
             ps.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth));
-            ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, 0.0f);
+            ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, b4.w);
             return true;
         }
         rng_counter = rng.counter;
@@ -1392,6 +1411,11 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         if (!(m.radius > 0.0f) || !(m.density > 0.0f) || m.texture < 0 || m.texture >= (int32_t)s->n_textures)
             return fail(ctx, PT_ERR_INVALID, "medium %u: radius and density must be positive and the texture must exist", i);
     }
+    if (s->n_moving > PTS_MAX_MOVING || s->n_moving > s->n_spheres || (s->n_moving && !s->moving))
+        return fail(ctx, PT_ERR_INVALID, "at most %d moving spheres, the last of spheres[], with their motion in a non-NULL array", (int)PTS_MAX_MOVING);
+    for (uint32_t k = 0; k < s->n_sets; k++)
+        if ((uint64_t)s->sets[k].spheres.prim_first + s->sets[k].spheres.prim_count > s->n_spheres - s->n_moving)
+            return fail(ctx, PT_ERR_INVALID, "set %u: moving spheres belong to no set", k);
     // a shade queue (and a shade kernel per bounce) only for material types some primitive uses
     bool type_present[MAX_QUEUES] = {false};
     type_present[PTD_MAT_MEDIUM] = s->n_media != 0;
@@ -1560,6 +1584,15 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     d.media = pmed;
     d.n_media = s->n_media;
     d.medium_queue = s->n_media ? (uint32_t)slot_of_type[PTD_MAT_MEDIUM] : 0xFFu;
+    {
+        std::vector<float4> delta(s->n_moving);
+        for (uint32_t i = 0; i < s->n_moving; i++) delta[i] = make_float4(s->moving[3 * i], s->moving[3 * i + 1], s->moving[3 * i + 2], 0.0f);
+        float4 *pd;
+        if ((rc = dev_upload(ctx, ctx->scene_allocs, &pd, delta.data(), delta.size()))) return rc;
+        d.moving_delta = pd;
+        d.n_moving = s->n_moving;
+        d.n_static_spheres = s->n_spheres - s->n_moving;
+    }
     d.world = sets[0];
     d.lights = sets[1];
     d.n_materials = s->n_materials;
@@ -1649,6 +1682,7 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
+    ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
     ps.nee = ctx->nee ? 1u : 0u;
     if (ctx->nee) {
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_queue, max_chunks * QUEUE_CHUNK))) return rc;
@@ -1686,8 +1720,13 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
     if (ctx->counters) {
         if (insts) { EXT(true, false); EXI(true); } else EXT(true, true);
     } else if (ctx->use_wide()) {
-        if (insts) hipLaunchKernelGGL((k_extend_walk<true>), g, b, 0, st, ctx->scene, ps, bounce, bg, new_base, n_new, ctx->stats);
-        else hipLaunchKernelGGL((k_extend_walk<false>), g, b, 0, st, ctx->scene, ps, bounce, bg, new_base, n_new, ctx->stats);
+#define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ps, bounce, bg, new_base, n_new, ctx->stats)
+        if (ctx->scene.n_moving != 0) {
+            if (insts) EXW(true, true); else EXW(false, true);
+        } else {
+            if (insts) EXW(true, false); else EXW(false, false);
+        }
+#undef EXW
     } else {
         if (insts) { EXT(false, false); EXI(false); } else EXT(false, true);
     }
@@ -1808,7 +1847,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     };
     // From the first bounce expected to carry fewer than tail_below rays, one launch finishes the batch.
     uint32_t tail_from = depth;
-    if (ctx->tail_below > 0 && !ctx->counters && !ctx->nee && ctx->scene.n_media == 0)
+    if (ctx->tail_below > 0 && !ctx->counters && !ctx->nee && ctx->scene.n_media == 0 && ctx->scene.n_moving == 0)
         for (uint32_t b = 1; b < depth; b++) {
             const uint64_t e = expected(b);
             if (e == 0) break;
@@ -1872,6 +1911,7 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
     if ((rc = dev_alloc(ctx, r.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.regions, (size_t)n_regions))) return rc;
+    ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
     ps.nee = ctx->nee ? 1u : 0u;
     if (ctx->nee) {
         if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_queue, max_chunks * QUEUE_CHUNK))) return rc;
@@ -2001,7 +2041,10 @@ static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
     if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PT_ERR_STATE, "upload a scene and set a camera before rendering");
     const uint64_t total = (uint64_t)ctx->cam.sqrt_spp * ctx->cam.sqrt_spp;
     if (b > e || e > total) return fail(ctx, PT_ERR_INVALID, "stratum range [%u,%u) outside [0,%llu)", b, e, (unsigned long long)total);
-    if (ctx->nee && ctx->scene.n_media != 0) return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation does not handle participating media");
+    if (ctx->nee && (ctx->scene.n_media != 0 || ctx->scene.n_moving != 0))
+        return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation does not handle participating media or moving spheres");
+    if (ctx->scene.n_moving != 0 && (ctx->counters || !ctx->use_wide()))
+        return fail(ctx, PT_ERR_UNSUPPORTED, "moving spheres are handled by the ray-drawing traversal only (no test counters, no reference-order traversal)");
     if (ctx->nee && (ctx->counters || !ctx->use_wide()))
         return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation runs on the ray-drawing traversal only (no test counters, no reference-order traversal)");
     return PT_OK;

@@ -651,6 +651,16 @@ void FlatScene::add_medium(Point3 center, float radius, float density, const Tex
     media_.push_back(m);
 }
 
+void FlatScene::add_moving_sphere(Point3 center0, Point3 center1, float radius, const MaterialRef &material) {
+    if (moving_.size() >= PTS_MAX_MOVING) throw std::runtime_error("too many moving spheres");
+    pts_moving_sphere m{};
+    m.center0[0] = center0.x; m.center0[1] = center0.y; m.center0[2] = center0.z;
+    m.center1[0] = center1.x; m.center1[1] = center1.y; m.center1[2] = center1.z;
+    m.radius = radius;
+    m.material = material_index(material);
+    moving_.push_back(m);
+}
+
 void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights) {
     add_set(objects);
     add_set(lights.objects);
@@ -666,6 +676,12 @@ void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights)
         const uint32_t child = add_set(*lights.objects.instances.buffer[k].obj);
         instances_[li.prim_first + k].child_set = child;
     }
+    // moving spheres go behind the spheres of the sets, as they are at time 0
+    for (const pts_moving_sphere &m : moving_) {
+        spheres_.insert(spheres_.end(), {m.center0[0], m.center0[1], m.center0[2], m.radius});
+        sphere_mat_.push_back(m.material);
+        for (int k = 0; k < 3; k++) moving_delta_.push_back(m.center1[k] - m.center0[k]);
+    }
     pt_scene_desc d{};
     d.n_tris = (uint32_t)tri_mat_.size(); d.tri_data = tri_data_.data(); d.tri_mat = tri_mat_.data();
     d.n_spheres = (uint32_t)sphere_mat_.size(); d.spheres = spheres_.data(); d.sphere_mat = sphere_mat_.data();
@@ -678,6 +694,7 @@ void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights)
     d.n_images = (uint32_t)images_.size(); d.images = images_.data();
     d.n_texel_bytes = texels_.size(); d.texels = texels_.data();
     d.n_media = (uint32_t)media_.size(); d.media = media_.data();
+    d.n_moving = (uint32_t)moving_.size(); d.moving = moving_delta_.data();
     desc_ = d;
 }
 
@@ -919,6 +936,13 @@ pth_scene *pth_scene_build_opts(const pts_scene *scene, const pts_camera *camera
             if (m.texture < 0 || (size_t)m.texture >= L.tex.size()) throw std::runtime_error("medium: texture index out of range");
             if (!(m.radius > 0.0f) || !(m.density > 0.0f)) throw std::runtime_error("medium: radius and density must be positive");
             out->flat.add_medium(Point3(m.center[0], m.center[1], m.center[2]), m.radius, m.density, L.tex[m.texture]);
+        }
+        if (scene->n_moving && !scene->moving) throw std::runtime_error("moving is NULL");
+        for (uint32_t k = 0; k < scene->n_moving; k++) {
+            const pts_moving_sphere &m = scene->moving[k];
+            if (m.material < -1 || m.material >= (int32_t)L.mat.size()) throw std::runtime_error("moving sphere: material index out of range");
+            out->flat.add_moving_sphere(Point3(m.center0[0], m.center0[1], m.center0[2]), Point3(m.center1[0], m.center1[1], m.center1[2]), m.radius,
+                                        m.material >= 0 ? L.mat[m.material] : MaterialRef());
         }
         out->flat.build(out->objects, out->lights);
         const pts_camera &c = *camera;

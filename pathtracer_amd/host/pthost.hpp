@@ -268,6 +268,8 @@ public:
     const pt_scene_desc &desc() const { return desc_; }
     // Participating media (pts_medium; not in the reference).  Call before build().
     void add_medium(Point3 center, float radius, float density, const TextureRef &albedo);
+    // Moving spheres (pts_moving_sphere; not in the reference).  Call before build().
+    void add_moving_sphere(Point3 center0, Point3 center1, float radius, const MaterialRef &material);
 
 private:
     uint32_t add_set(const PrimitiveBuffer &pb);
@@ -283,6 +285,8 @@ private:
     std::vector<pts_image> images_;
     std::vector<uint8_t> texels_;
     std::vector<pts_medium> media_;
+    std::vector<pts_moving_sphere> moving_;
+    std::vector<float> moving_delta_;
     std::unordered_map<const Material *, int> mat_ids_;
     std::unordered_map<const Texture *, int> tex_ids_;
     std::unordered_map<const RgbImage *, int> img_ids_;

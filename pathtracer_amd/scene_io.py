@@ -43,6 +43,7 @@ def scene_to_arrays(src: SceneSource) -> dict:
     meta = {"name": src.name, "sets": sets, "lights_index": lights_index,
             "textures": [[t[0], list(t[1]), t[2], t[3], t[4], t[5]] for t in src.textures],
             "media": [[list(m[0]), m[1], m[2], m[3]] for m in src.media],
+            "moving": [[list(m[0]), list(m[1]), m[2], m[3]] for m in src.moving],
             "materials": [[m[0], m[1], list(m[2])] for m in src.materials],
             "camera": [cam.aspect_ratio, cam.image_width, cam.vfov, list(cam.look_from), list(cam.look_at), cam.focal_length,
                        cam.defocus_angle, cam.spp, cam.max_depth, list(cam.background)]}
@@ -80,6 +81,7 @@ def scene_from_arrays(a) -> SceneSource:
     src.name = meta["name"]
     src.textures = [(t[0], tuple(t[1]), t[2], t[3], t[4], t[5]) for t in meta["textures"]]
     src.media = [(tuple(m[0]), m[1], m[2], m[3]) for m in meta.get("media", [])]
+    src.moving = [(tuple(m[0]), tuple(m[1]), m[2], m[3]) for m in meta.get("moving", [])]
     src.materials = [(m[0], m[1], list(m[2])) for m in meta["materials"]]
     k = 0
     while f"image_{k}" in a:

@@ -66,6 +66,10 @@ class pts_medium(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("density", C.c_float), ("texture", C.c_int32)]
 
 
+class pts_moving_sphere(C.Structure):
+    _fields_ = [("center0", C.c_float * 3), ("center1", C.c_float * 3), ("radius", C.c_float), ("material", C.c_int32)]
+
+
 class pts_scene(C.Structure):
     _fields_ = [
         ("n_textures", C.c_uint32), ("textures", C.POINTER(pts_texture)),
@@ -80,6 +84,7 @@ class pts_scene(C.Structure):
         ("n_ops", C.c_uint32), ("ops", C.POINTER(pts_xform_op)),
         ("n_sets", C.c_uint32), ("sets", C.POINTER(pts_primset)),
         ("n_media", C.c_uint32), ("media", C.POINTER(pts_medium)),
+        ("n_moving", C.c_uint32), ("moving", C.POINTER(pts_moving_sphere)),
     ]
 
 
@@ -227,7 +232,12 @@ class SceneSource:
         self.camera: Optional[CameraSrc] = None
         self.name = ""
         self.media: List[tuple] = []
+        self.moving: List[tuple] = []
         self._keep = None
+
+    def add_moving_sphere(self, center0, center1, radius: float, material: int):
+        """A sphere moving from ``center0`` (time 0) to ``center1`` (time 1) (``pts_moving_sphere``; not in the reference)."""
+        self.moving.append((tuple(float(c) for c in center0), tuple(float(c) for c in center1), float(radius), int(material)))
 
     def add_medium(self, center, radius: float, density: float, albedo_texture: int):
         """A homogeneous medium filling a sphere (``pts_medium``; not in the reference)."""
@@ -383,7 +393,11 @@ class SceneSource:
         for k, (center, radius, density, tex) in enumerate(self.media):
             cmed[k].center[:] = center; cmed[k].radius = radius; cmed[k].density = density; cmed[k].texture = tex
         sc.n_media = len(self.media); sc.media = C.cast(cmed, C.POINTER(pts_medium))
+        cmov = (pts_moving_sphere * max(1, len(self.moving)))()
+        for k, (c0, c1, radius, mat) in enumerate(self.moving):
+            cmov[k].center0[:] = c0; cmov[k].center1[:] = c1; cmov[k].radius = radius; cmov[k].material = mat
+        sc.n_moving = len(self.moving); sc.moving = C.cast(cmov, C.POINTER(pts_moving_sphere))
         cam = self.camera.to_c()
-        self._keep = (cmed, a_tri_pos, a_tri_nrm, a_tri_uv, a_tri_flags, a_tri_mat, a_spheres, a_sphere_mat, a_quads,
+        self._keep = (cmed, cmov, a_tri_pos, a_tri_nrm, a_tri_uv, a_tri_flags, a_tri_mat, a_spheres, a_sphere_mat, a_quads,
                       a_quad_mat, ctex, cimg, a_texels, cmat, cinst, cops, csets, sc, cam)
         return sc, cam

@@ -319,8 +319,8 @@ def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed:
     """The primitives-only part of the "Next Week" final scene: a floor of boxes (instances), an emissive
     quad, glass / metal / textured spheres and a rotated, translated cluster of ~1000 small spheres.
     Volumes, Perlin noise and motion blur do not exist in the reference; ``extensions`` adds the ones this
-    build has of its own: the marble sphere's noise texture, the blue medium inside the second glass sphere
-    and the thin mist around everything."""
+    build has of its own: the marble sphere's noise texture, the blue medium inside the second glass sphere,
+    the thin mist around everything and the motion of the orange sphere."""
     s = SceneSource()
     s.name = "next_week_like"
     ground = s.lambertian((0.48, 0.83, 0.53))
@@ -345,7 +345,10 @@ def next_week_like(width: int = 800, spp: int = 1024, max_depth: int = 50, seed:
     q = ((123.0, 554.0, 147.0), (300.0, 0.0, 0.0), (0.0, 0.0, 265.0))
     o.add_quad(*q, light)
     s.lights.add_quad(*q, light)
-    o.add_sphere((400.0, 400.0, 200.0), 50.0, orange)
+    if extensions:
+        s.add_moving_sphere((400.0, 400.0, 200.0), (430.0, 400.0, 200.0), 50.0, orange)
+    else:
+        o.add_sphere((400.0, 400.0, 200.0), 50.0, orange)
     o.add_sphere((260.0, 150.0, 45.0), 50.0, glass)
     o.add_sphere((0.0, 150.0, 145.0), 50.0, metal)
     o.add_sphere((360.0, 150.0, 145.0), 70.0, glass)

@@ -1,0 +1,85 @@
+"""Moving spheres (pts_moving_sphere) are not in the reference; the oracle states them, the device library restates
+them.  CPU part: what the oracle's statement must satisfy on its own.  GPU part: the device against the oracle."""
+import numpy as np
+import pytest
+
+from pathtracer_amd import scenes
+from pathtracer_amd.scene_src import CameraSrc, SceneSource
+
+
+def _scene(c0, c1, width=48, spp=64, depth=1, extras=False):
+    """An emissive sphere of radius 1 moving from c0 to c1 in front of a black background, seen from z = -12."""
+    s = SceneSource()
+    s.name = "moving"
+    emit = s.diffuse_light((1.0, 1.0, 1.0))
+    s.objects.add_quad((-1, 60, -1), (2, 0, 0), (0, 0, 2), emit)  # keeps the light list non-empty, out of sight
+    s.lights.add_quad((-1, 60, -1), (2, 0, 0), (0, 0, 2), emit)
+    if extras:
+        s.objects.add_quad((-8, -2, -8), (16, 0, 0), (0, 0, 16), s.lambertian((0.6, 0.6, 0.6)))
+        s.objects.add_sphere((-2.5, -1.0, 1.0), 1.0, s.metal((0.8, 0.8, 0.8), 0.1))
+        s.objects.add_quad((-2, 6, -2), (4, 0, 0), (0, 0, 4), emit)
+        s.lights.add_quad((-2, 6, -2), (4, 0, 0), (0, 0, 4), emit)
+        s.objects.build_bvh = True
+        s.add_moving_sphere((2.0, -1.0, 0.0), (2.0, 0.5, 0.0), 1.0, s.lambertian((0.7, 0.3, 0.2)))
+    s.add_moving_sphere(c0, c1, 1.0, emit)
+    s.camera = CameraSrc(1.0, width, 40.0, (0.0, 0.0, -12.0), (0.0, 0.0, 0.0), 12.0, 0.0, spp, depth, (0.0, 0.0, 0.0))
+    return s
+
+
+def test_a_sphere_that_does_not_move_is_a_sphere():
+    from oracle.pyoracle import OracleScene
+    a = OracleScene(_scene((0.5, 0.25, 0.0), (0.5, 0.25, 0.0))).render(0, 16, seed=2)["accum"]
+    s = _scene((0.5, 0.25, 0.0), (0.5, 0.25, 0.0))
+    s.moving = []
+    s.objects.add_sphere((0.5, 0.25, 0.0), 1.0, 0)  # material 0 is the emitter
+    b = OracleScene(s).render(0, 16, seed=2)["accum"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_the_streak_covers_the_swept_area_with_the_right_exposure():
+    """Moving by 3 radii along x: a pixel on the axis of motion is lit for the fraction of the exposure during which
+    the disc covers it, the total light is that of the still sphere, and the streak is as long as the sweep."""
+    from oracle.pyoracle import OracleScene
+    n = 256
+    still = OracleScene(_scene((-1.5, 0.0, 0.0), (-1.5, 0.0, 0.0), spp=n)).render(0, n, seed=1)["accum"].reshape(48, 48, 3)[..., 0] / n
+    moved = OracleScene(_scene((-1.5, 0.0, 0.0), (1.5, 0.0, 0.0), spp=n)).render(0, n, seed=1)["accum"].reshape(48, 48, 3)[..., 0] / n
+    assert abs(moved.sum() - still.sum()) <= 0.03 * still.sum()
+    row = moved[24]
+    lit = np.nonzero(row > 0.02)[0]
+    width_still = np.count_nonzero(still[24] > 0.5)
+    assert abs((lit[-1] - lit[0] + 1) - (width_still * 2.5)) <= 3  # sweep of 3 radii + the disc's own 2 radii = 2.5 discs
+    centre = row[24 - 2:24 + 2].mean()  # the disc (2 radii wide) passes over the centre during 2/3 of the exposure
+    assert abs(centre - 2.0 / 3.0) < 0.08, centre
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["moving", "next_week"])
+def test_device_restatement_against_the_oracle_per_sample(which):
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import PT_OPT_PIPES, PT_OPT_ROLLING, HostScene, Renderer
+    src = (_scene((-1.5, 0.0, 0.0), (1.5, 0.3, 0.5), width=40, spp=36, depth=10, extras=True) if which == "moving"
+           else scenes.next_week_like(40, 36, max_depth=12, extensions=True))
+    o, r = OracleScene(src), Renderer(HostScene(src))
+    ref = np.nan_to_num(o.render(0, 4, seed=5, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 4, seed=5), nan=0.0, posinf=0.0, neginf=0.0)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() > 0.99, close.mean()
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
+    accs = []
+    for pipes, rolling in ((1, 0), (2, 3 * 40 * 40)):
+        r2 = Renderer(HostScene(src))
+        r2.set_option(PT_OPT_PIPES, pipes)
+        r2.set_option(PT_OPT_ROLLING, rolling)
+        r2.render(0, 20, seed=7)
+        accs.append(r2.read_accum()[0])
+    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_modes_that_do_not_handle_moving_spheres_say_so():
+    from pathtracer_amd.core import PT_OPT_INTEGRATOR, PT_OPT_TRAVERSAL, HostScene, PtError, Renderer
+    for key in (PT_OPT_INTEGRATOR, PT_OPT_TRAVERSAL):
+        r = Renderer(HostScene(_scene((0, 0, 0), (1, 0, 0), depth=4, spp=4)))
+        r.set_option(key, 1)
+        with pytest.raises(PtError):
+            r.render(0, 1, seed=1)
