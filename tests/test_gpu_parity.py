@@ -190,7 +190,7 @@ def test_error_codes_instead_of_crashes():
 
 
 def test_full_size_properties_knob_768():
-    """BASELINE configuration size (768x768, depth 50): size-independent properties only."""
+    """The benchmark configuration at its full size (768x768, depth 50): size-independent properties only."""
     src = scenes.knob(768, 10240, 50)
     from pathtracer_amd.core import HostScene, Renderer
     r = Renderer(HostScene(src))
