@@ -917,6 +917,7 @@ struct pt_context {
     Pipe pipes[MAX_PIPES];
     Roll rolls[MAX_PIPES];
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
+    int64_t roll_k = -1;             // strata per tick decided for the current scene, camera and options (-1: not yet)
     uint64_t roll_paths = 1u << 23;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;       // batch-at-a-time schedule
     int n_roll_pipes = 2;  // rolling schedule: its launches are all large, two pipes cover each other's ramps
@@ -1173,6 +1174,7 @@ int pt_set_option(pt_context *ctx, int key, double value) {
     if (!ctx) return PT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     sync_pipes(ctx);  // batches under way finish under the settings they started with
+    ctx->roll_k = -1;
     switch (key) {
         case PT_OPT_BSDF_SAMPLE_PROBABILITY:
             if (!(value >= 0.0 && value <= 1.0)) return fail(ctx, PT_ERR_INVALID, "bsdf sample probability must be in [0,1]");
@@ -1612,6 +1614,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         pp.capacity = 0;
     }
     for (auto &r : ctx->rolls) free_roll(ctx, r);
+    ctx->roll_k = -1;
     return PT_OK;
 }
 
@@ -1653,6 +1656,7 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
     ctx->n_samples = 0;
     ctx->cam = d;
     ctx->have_camera = true;
+    ctx->roll_k = -1;
     return PT_OK;
 }
 
@@ -2020,7 +2024,14 @@ static int roll_flush(pt_context *ctx) {
 
 // Strata per tick of the rolling schedule for the current camera, 0 when the batch-at-a-time schedule is
 // to be used (switched off, counting or reference-order traversal, or the regions would not fit).
+static uint32_t roll_strata_now(pt_context *ctx);
 static uint32_t roll_strata(pt_context *ctx) {
+    // decided once per scene / camera / option change: the answer depends on the free memory at that time, and
+    // a different one later would mean reallocating the path state in the middle of a render
+    if (ctx->roll_k < 0) ctx->roll_k = (int64_t)roll_strata_now(ctx);
+    return (uint32_t)ctx->roll_k;
+}
+static uint32_t roll_strata_now(pt_context *ctx) {
     const uint32_t depth = ctx->cam.max_depth;
     if (ctx->roll_paths == 0 || ctx->counters || !ctx->use_wide() || depth == 0 || depth > 256) return 0;
     const uint64_t npix = (uint64_t)ctx->cam.width * ctx->cam.height;
