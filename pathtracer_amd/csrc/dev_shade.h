@@ -653,6 +653,34 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
     return pdf / (float)sc.n_light_total;
 }
 
+// What light_pdf contributes when its weight in the mixture is zero (BSDF_SAMPLE_PROBABILITY = 1,
+// src/camera.rs:317, :339-340): `0 * light_pdf` is 0 unless light_pdf is NaN or infinite.  Triangle and
+// quad terms are finite whenever the primitive is hit at all (a hit needs a non-degenerate triangle,
+// and a quad's |denominator| >= 1e-6).  A sphere's term, 1 / (2 pi (1 - sqrt(1 - r^2 / |c - o|^2))), is
+// NaN when the origin lies inside the sphere and infinite when the sphere is so small or far that the
+// root rounds to 1; it counts only if the ray hits that sphere.  So this returns 0, or NaN in those
+// cases, from the sphere lights' own terms: the intersection test per light and vertex of the full sum
+// is not needed for a product with zero.
+__device__ inline float light_pdf_times_zero(const DevScene &sc, f3 o, f3 d) {
+    const DevSet &L = sc.lights;
+    float r = 0.0f;
+    TravCounters tc{0, 0, 0, 0};
+    for (uint32_t i = 0; i < L.spheres.prim_count; i++) {
+        const uint32_t g = L.spheres.prim_first + i;
+        const float4 s = sc.spheres[g];
+        const float cos_theta_max = sqrtf(1.0f - s.w * s.w / norm_squared(mk3(s.x, s.y, s.z) - o));
+        const float term = 1.0f / (2.0f * PTD_PI * (1.0f - cos_theta_max));
+        if (!(fabsf(term) <= 3.0e38f)) {
+            TravRay ray = make_trav_ray(o, d, 0.001f, INFINITY);
+            HitState h;
+            h.code = PTD_HIT_MISS;
+            hit_prim<PT_PRIM_SPHERE>(sc, g, ray, h, 0u, tc);
+            if (h.code != PTD_HIT_MISS) r = NAN;
+        }
+    }
+    return r;
+}
+
 // LightBuffer::sample: uniform pick, then the primitive's sampler; returns the unnormalised
 // vector from `origin` towards the sampled point.
 // Sphere::sample of the reference puts its cone around the basis' third axis while

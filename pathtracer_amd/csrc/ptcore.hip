@@ -460,7 +460,8 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
             }
             if (!is_bsdf) depth = 2u;
             const float scatter_pdf = mat_pdf<MT>(m, w_out, w_in, s);
-            const float l_pdf = light_pdf(sc, s.p, w_in_world);
+            // with probability 1 for BSDF sampling the light term is a product with zero: 0, or NaN
+            const float l_pdf = bp.bsdf_prob == 1.0f ? light_pdf_times_zero(sc, s.p, w_in_world) : light_pdf(sc, s.p, w_in_world);
             const float pdf = bp.bsdf_prob * scatter_pdf + (1.0f - bp.bsdf_prob) * l_pdf;
             const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
             const float cosv = fabsf(w_in.y);

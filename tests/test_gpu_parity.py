@@ -206,3 +206,33 @@ def test_full_size_properties_knob_768():
     assert st["paths"] == 2 * 4 * 768 * 768 and st["rays"] >= st["paths"]
     img = r.read_rgb8()
     assert img.shape == (768, 768, 3) and img.mean() > 1.0
+
+
+def test_vertices_inside_a_sphere_light_poison_their_paths_as_in_the_reference():
+    """LightBuffer::pdf is NaN for an origin inside a sphere light (src/objects/sphere.rs:109-120) and the reference
+    multiplies it by zero (src/camera.rs:339-340), which kills the path.  The device skips the sum over the lights
+    when its weight is zero and must still reproduce that."""
+    from pathtracer_amd.scene_src import CameraSrc, SceneSource
+    s = SceneSource()
+    s.name = "inside_a_light"
+    emit = s.diffuse_light((3.0, 3.0, 3.0))
+    grey = s.lambertian((0.7, 0.7, 0.7))
+    o = s.objects
+    o.add_sphere((0.0, 0.0, 0.0), 6.0, emit)          # encloses the two grey spheres: seen from inside it emits nothing
+    s.lights.add_sphere((0.0, 0.0, 0.0), 6.0, emit)
+    o.add_quad((-1, 3, -1), (2, 0, 0), (0, 0, 2), emit)
+    s.lights.add_quad((-1, 3, -1), (2, 0, 0), (0, 0, 2), emit)
+    o.add_sphere((-1.2, 0.0, 0.0), 1.0, grey)
+    o.add_sphere((1.2, 0.0, 0.0), 1.0, s.disney_diffuse((0.3, 0.3, 0.8), 1.0, 0.5))
+    o.add_sphere((12.0, 0.0, 0.0), 2.0, grey)         # outside the light sphere: ordinary shading
+    o.add_quad((8, -2, -6), (10, 0, 0), (0, 0, 12), grey)
+    o.build_bvh = True
+    s.camera = CameraSrc(1.0, 48, 60.0, (4.0, 2.0, -16.0), (4.0, 0.0, 0.0), 10.0, 0.0, 16, 8, (0.2, 0.2, 0.2))
+    o_, r = _pair(s)
+    ref = o_.render(0, 6, seed=3, iterative=True, per_sample=True)["per_sample"]
+    got = r.render_samples(0, 6, seed=3)
+    assert np.array_equal(np.isnan(ref), np.isnan(got))
+    ref, got = np.nan_to_num(ref), np.nan_to_num(got)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() > 0.995, close.mean()
+    assert ref.sum() > 0
