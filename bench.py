@@ -213,6 +213,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
                          "launches": st["extend_launches"], "busy_ms": st["extend_busy_ms"],
+                         "achieved_per_launch": (rays_per_launch * b_ray / (ext_ms_per_launch * 1e-3) / 1e9) if ext_ms_per_launch > 0 else 0.0,
                          "launches_in_flight": st["extend_ms"] / st["extend_busy_ms"] if st["extend_busy_ms"] > 0 else 0.0,
                          "node_tests_per_ray": sc["node_tests"] / rays_c, "tri_tests_per_ray": sc["tri_tests"] / rays_c},
             "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "other": st["other_ms"]},
