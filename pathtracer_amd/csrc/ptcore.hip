@@ -856,7 +856,7 @@ struct pt_context {
 #ifdef PT_WALK_WAVES
     int blocks_per_cu = PT_WALK_WAVES;
 #else
-    int blocks_per_cu = 4;
+    int blocks_per_cu = 5;  // as many as the LDS stacks allow: measured 0.4 - 4 % faster than 4 on every scene
 #endif
     int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
     bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
