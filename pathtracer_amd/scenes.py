@@ -431,3 +431,26 @@ def small_mixed(width: int = 64, spp: int = 16, max_depth: int = 12, seed: int =
     o.build_bvh = True
     s.camera = CameraSrc(1.0, width, 50.0, (0.0, 4.0, -11.0), (0.0, 3.0, 0.0), 10.0, 0.6, spp, max_depth, (0.1, 0.12, 0.2))
     return s
+
+
+def extensions_demo(width: int = 64, spp: int = 16, max_depth: int = 10) -> SceneSource:
+    """A small scene with the three things this build adds to the reference's vocabulary: a noise texture, a
+    participating medium and a moving sphere, next to ordinary geometry."""
+    s = SceneSource()
+    s.name = "extensions_demo"
+    marble = s.lambertian_texture(s.noise((0.5, 0.5, 0.5), 0.8, 5))
+    veined = s.lambertian_texture(s.checkered(s.noise((0.8, 0.3, 0.2), 1.5, 3), s.solid((0.25, 0.25, 0.25)), 4.0))
+    emit = s.diffuse_light((5.0, 5.0, 4.5))
+    o = s.objects
+    o.add_quad((-10.0, 0.0, -10.0), (20.0, 0.0, 0.0), (0.0, 0.0, 20.0), veined)
+    o.add_sphere((-2.2, 1.0, 0.5), 1.0, marble)
+    o.add_sphere((0.0, 1.0, -1.0), 1.0, s.dielectric(1.5))
+    o.add_sphere((2.4, 0.8, 2.0), 0.8, s.metal((0.8, 0.8, 0.7), 0.2))
+    o.add_quad((-2.0, 6.0, -2.0), (4.0, 0.0, 0.0), (0.0, 0.0, 4.0), emit)
+    s.lights.add_quad((-2.0, 6.0, -2.0), (4.0, 0.0, 0.0), (0.0, 0.0, 4.0), emit)
+    o.build_bvh = True
+    s.add_medium((0.0, 1.0, -1.0), 1.0, 1.5, s.solid((0.2, 0.4, 0.9)))      # inside the glass sphere
+    s.add_medium((0.0, 0.0, 0.0), 30.0, 0.02, s.solid((1.0, 1.0, 1.0)))     # mist
+    s.add_moving_sphere((2.0, 2.6, -1.5), (2.8, 2.9, -1.5), 0.6, s.lambertian((0.7, 0.3, 0.1)))
+    s.camera = CameraSrc(1.0, width, 35.0, (0.0, 3.0, -12.0), (0.0, 1.2, 0.0), 12.0, 0.0, spp, max_depth, (0.35, 0.45, 0.7))
+    return s

@@ -34,7 +34,7 @@ def bvh_digest(o: OracleScene) -> str:
     return h.hexdigest()
 
 
-def make(name, src, n_strata=2, seed=11):
+def make(name, src, n_strata=2, seed=11, nee=False):
     o = OracleScene(src)
     rays = o.primary_rays()
     ids, tuv = o.trace(rays)
@@ -46,10 +46,18 @@ def make(name, src, n_strata=2, seed=11):
         camera_constants=o.camera_constants(), first_hit_ids=ids, first_hit_tuv=tuv, jittered_rays_stratum1=jit,
         per_sample_recursive=rec["per_sample"], per_sample_iterative=it["per_sample"], rays_traced=np.array([rec["rays"]], np.uint64),
         bvh_sha256=np.frombuffer(bvh_digest(o).encode(), np.uint8), seed=np.array([seed], np.uint64), n_strata=np.array([n_strata], np.uint32))
+    if nee:  # the next-event estimator of this build (not in the reference): ray_color_nee
+        out["per_sample_nee"] = o.render(0, n_strata, seed=seed, iterative=2, per_sample=True)["per_sample"]
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "rays", rec["rays"], "hits", int((ids[:, 0] >= 0).sum()), "of", ids.shape[0])
 
 
 if __name__ == "__main__":
-    make("cornell_48", scenes.cornell(48, 16, 16))
-    make("small_mixed_40", scenes.small_mixed(40, 16, 12))
+    which = sys.argv[1:]  # names to (re)write; none = all.  Existing fixtures are only rewritten on purpose.
+    todo = {"cornell_48": lambda: make("cornell_48", scenes.cornell(48, 16, 16)),
+            "small_mixed_40": lambda: make("small_mixed_40", scenes.small_mixed(40, 16, 12)),
+            "small_mixed_nee_32": lambda: make("small_mixed_nee_32", scenes.small_mixed(32, 16, 12), nee=True),
+            "extensions_demo_40": lambda: make("extensions_demo_40", scenes.extensions_demo(40, 16, 10))}
+    for name, fn in todo.items():
+        if not which or name in which:
+            fn()

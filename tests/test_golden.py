@@ -11,7 +11,7 @@ from pathtracer_amd.scene_io import scene_from_arrays
 from tests.util import bits_equal
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NAMES = ["cornell_48", "small_mixed_40"]
+NAMES = ["cornell_48", "small_mixed_40", "small_mixed_nee_32", "extensions_demo_40"]
 
 
 def _load(name):
@@ -43,6 +43,9 @@ def test_oracle_reproduces_fixture(name):
     # radiance goes through libm (sin/cos/pow/acos/atan2/log2): allow last-bit differences between C libraries
     x, y = np.nan_to_num(r["per_sample"]), np.nan_to_num(a["per_sample_recursive"])
     assert np.allclose(x, y, rtol=1e-5, atol=1e-7)
+    if "per_sample_nee" in a:
+        x = np.nan_to_num(o.render(0, n, seed=seed, iterative=2, per_sample=True)["per_sample"])
+        assert np.allclose(x, np.nan_to_num(a["per_sample_nee"]), rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.gpu
@@ -62,3 +65,10 @@ def test_device_matches_fixture(name):
     ref = np.nan_to_num(a["per_sample_iterative"], nan=0.0, posinf=0.0, neginf=0.0)
     close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
     assert close.mean() > 0.99
+    if "per_sample_nee" in a:
+        from pathtracer_amd.core import PT_OPT_INTEGRATOR
+        r.set_option(PT_OPT_INTEGRATOR, 1)
+        got = np.nan_to_num(r.render_samples(0, n, seed), nan=0.0, posinf=0.0, neginf=0.0)
+        ref = np.nan_to_num(a["per_sample_nee"], nan=0.0, posinf=0.0, neginf=0.0)
+        close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+        assert close.mean() > 0.99
