@@ -7,7 +7,7 @@ CXX ?= g++
 ARCH ?= gfx950
 # FMA contraction off + correctly rounded f32 divide/sqrt: first-hit ids are compared in bits
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -std=c++17 -Wall
-HOSTFLAGS = -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -std=c++17 -Wall -Wextra
+HOSTFLAGS = -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -std=c++17 -Wall -Wextra -pthread
 
 CORE_SRC = pathtracer_amd/csrc/ptcore.hip pathtracer_amd/csrc/bvh_build.hip
 CORE_DEP = $(wildcard pathtracer_amd/csrc/*.h) include/ptcore.h include/ptscene_src.h

@@ -3,8 +3,14 @@
 #include "pthost.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <deque>
+#include <list>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -408,21 +414,34 @@ namespace {
 constexpr int kBuckets = 12;
 constexpr size_t kMaxLeaf = 3;
 
+// The tree is found first (large subtrees on their own threads: they work on disjoint parts of `order`)
+// and written out in pre-order afterwards, the two steps of BVHBuilder::build_bvh and flatten_bvh
+// (src/bvh.rs:313-516).  What each node decides depends on its own range only, so the result does not
+// depend on the number of threads.
+struct TreeNode {
+    BBox bbox;
+    uint32_t start = 0, size = 0;  // leaf: its range of `order`
+    int axis = -1;                 // interior: split axis, children below
+    TreeNode *left = nullptr, *right = nullptr;
+};
+// Nodes of one thread's subtrees (addresses stay valid while the deque grows).
+using Arena = std::deque<TreeNode>;
+
 struct BuildCtx {
+    BuildCtx(const std::vector<BBox> &b, std::vector<uint32_t> &o) : boxes(b), order(o) {}
     const std::vector<BBox> &boxes;
     std::vector<Point3> centroids;  // per original primitive
     std::vector<uint32_t> &order;
-    std::vector<pt_node> &nodes;
+    std::atomic<int> spare_threads{0};
+    std::atomic<bool> failed{false};
+    std::mutex arenas_lock;
+    std::list<Arena> arenas;
+    Arena &new_arena() {
+        std::lock_guard<std::mutex> g(arenas_lock);
+        arenas.emplace_back();
+        return arenas.back();
+    }
 };
-
-pt_node make_node(const BBox &b, uint32_t a, uint32_t bb) {
-    pt_node n;
-    n.bmin[0] = b.min.x; n.bmin[1] = b.min.y; n.bmin[2] = b.min.z;
-    n.bmax[0] = b.max.x; n.bmax[1] = b.max.y; n.bmax[2] = b.max.z;
-    n.a = a;
-    n.b = bb;
-    return n;
-}
 
 // `(12.0 * offset) as usize` then min(11): saturating conversion, NaN -> 0
 int bucket_index(const BBox &cb, Point3 c, int axis) {
@@ -432,15 +451,22 @@ int bucket_index(const BBox &cb, Point3 c, int axis) {
     return (int)std::min<long long>(b, kBuckets - 1);
 }
 
-// Emits the subtree over order[start, end) in pre-order. Returns false past depth 63.
-bool emit(BuildCtx &c, size_t start, size_t end, uint32_t depth) {
-    if (depth > 63) return false;
+// The subtree over order[start, end); null (and c.failed) past depth 63 or on an empty side.
+TreeNode *grow(BuildCtx &c, Arena &arena, size_t start, size_t end, uint32_t depth) {
+    if (depth > 63 || c.failed.load(std::memory_order_relaxed)) {
+        c.failed = true;
+        return nullptr;
+    }
+    arena.emplace_back();
+    TreeNode *node = &arena.back();
     BBox bbox = c.boxes[c.order[start]];
     for (size_t i = start; i < end; i++) bbox = bbox.merge(c.boxes[c.order[i]]);
+    node->bbox = bbox;
     const size_t size = end - start;
     auto leaf = [&]() {
-        c.nodes.push_back(make_node(bbox, (uint32_t)start, PT_NODE_LEAF | (uint32_t)(uint16_t)size));
-        return true;
+        node->start = (uint32_t)start;
+        node->size = (uint32_t)size;
+        return node;
     };
     if (size == 1) return leaf();
     const int axis = bbox.longest_axis();
@@ -502,25 +528,76 @@ bool emit(BuildCtx &c, size_t start, size_t end, uint32_t depth) {
         }
         mid = i + 1;
     }
-    const size_t self = c.nodes.size();
-    c.nodes.push_back(make_node(bbox, 0u, (uint32_t)axis));
+    node->axis = axis;
     if (mid <= start || mid >= end) {
         // The reference would recurse into an empty range here and hit its `start < end` assertion.
-        return false;
+        c.failed = true;
+        return nullptr;
     }
-    if (!emit(c, start, mid, depth + 1)) return false;
-    c.nodes[self].a = (uint32_t)c.nodes.size();
-    return emit(c, mid, end, depth + 1);
+    constexpr size_t kOwnThread = 1u << 14;  // smaller subtrees are not worth a thread
+    if (mid - start >= kOwnThread && end - mid >= kOwnThread && c.spare_threads.fetch_sub(1) > 0) {
+        TreeNode *left = nullptr;
+        std::thread t([&] { left = grow(c, c.new_arena(), start, mid, depth + 1); });
+        node->right = grow(c, arena, mid, end, depth + 1);
+        t.join();
+        c.spare_threads.fetch_add(1);
+        node->left = left;
+    } else {
+        if (mid - start >= kOwnThread && end - mid >= kOwnThread) c.spare_threads.fetch_add(1);  // undo the probe
+        node->left = grow(c, arena, start, mid, depth + 1);
+        node->right = grow(c, arena, mid, end, depth + 1);
+    }
+    if (!node->left || !node->right) return nullptr;
+    return node;
+}
+
+pt_node make_node(const BBox &b, uint32_t a, uint32_t bb) {
+    pt_node n;
+    n.bmin[0] = b.min.x; n.bmin[1] = b.min.y; n.bmin[2] = b.min.z;
+    n.bmax[0] = b.max.x; n.bmax[1] = b.max.y; n.bmax[2] = b.max.z;
+    n.a = a;
+    n.b = bb;
+    return n;
+}
+
+// flatten_bvh: pre-order, the left child follows its parent, `a` of an interior node is its right child.
+void flatten(const TreeNode &root, std::vector<pt_node> &nodes) {
+    struct Item {
+        const TreeNode *node;
+        int64_t parent;  // interior node whose right child this is, or -1
+    };
+    std::vector<Item> stack{{&root, -1}};
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.parent >= 0) nodes[(size_t)it.parent].a = (uint32_t)nodes.size();
+        const TreeNode &n = *it.node;
+        if (n.axis < 0) {
+            nodes.push_back(make_node(n.bbox, n.start, PT_NODE_LEAF | (uint32_t)(uint16_t)n.size));
+        } else {
+            const int64_t self = (int64_t)nodes.size();
+            nodes.push_back(make_node(n.bbox, 0u, (uint32_t)n.axis));
+            stack.push_back({n.right, self});
+            stack.push_back({n.left, -1});
+        }
+    }
 }
 }  // namespace
 
 bool BVHBuilder::build(const std::vector<BBox> &boxes, std::vector<uint32_t> &order, std::vector<pt_node> &nodes) {
     nodes.clear();
     if (boxes.empty()) return true;
-    BuildCtx c{boxes, {}, order, nodes};
+    BuildCtx c(boxes, order);
     c.centroids.reserve(boxes.size());
     for (const BBox &b : boxes) c.centroids.push_back(b.centroid());
-    return emit(c, 0, boxes.size(), 0);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("PTH_BUILD_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));  // 1 = no extra threads
+    c.spare_threads = (int)std::min(15u, hw > 1 ? hw - 1 : 0u);
+    TreeNode *root = grow(c, c.new_arena(), 0, boxes.size(), 0);
+    if (!root || c.failed) return false;
+    nodes.reserve(2 * boxes.size());
+    flatten(*root, nodes);
+    return true;
 }
 
 template <class T>

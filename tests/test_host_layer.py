@@ -105,3 +105,19 @@ def test_deep_tree_is_rejected_like_the_reference_panics():
     else:
         with pytest.raises(PtError, match="63"):
             HostScene(s)
+
+
+def test_builder_gives_the_same_tree_for_any_number_of_threads(monkeypatch):
+    """Large subtrees are grown on their own threads (the small test scenes never get there): same nodes, same order."""
+    import ctypes as C
+    from pathtracer_amd.core import PT_PRIM_TRI, HostScene, host_lib
+    src = scenes.knob(32, 4)  # 184 k triangles
+    got = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("PTH_BUILD_THREADS", threads)
+        h = HostScene(src)
+        buf = h.set_desc(0).tris
+        perm = np.zeros(buf.prim_count, np.uint32)
+        host_lib().pth_perm(h.h, 0, PT_PRIM_TRI, perm.ctypes.data_as(C.c_void_p))
+        got.append((h.nodes(buf).tobytes(), perm.tobytes(), h.triangles(buf).tobytes()))
+    assert got[0] == got[1]
