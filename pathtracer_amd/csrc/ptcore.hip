@@ -1,15 +1,17 @@
-// libptcore: the MI355X (gfx950) path-tracing core behind include/ptcore.h.
+// libptcore: the MI355X (gfx950) path-tracing core behind include/ptcore.h — the host side:
+// context, options, scene upload, path state, the two schedules and the entry points.  The
+// kernels are in dev_kernels.h.
 //
 // Wavefront organisation of Camera::render (src/camera.rs:162-236) and the recursion of
 // Camera::ray_color (src/camera.rs:262-373), unrolled: a batch holds every pixel of k
-// consecutive strata as independent paths; per bounce one `extend` launch finds closest
-// hits for the live rays and sorts the paths by material type into per-type queues, and
-// one `shade_<material>` launch per material type present in the scene evaluates the
-// vertex, applies Russian roulette and appends the survivors to the next ray queue.
-// Queue tails are reserved with one atomic per wave (wave64 ballot + mbcnt prefix).
-// Launch sizes are read from device memory, so a whole batch is enqueued without any
-// host synchronisation.  Finished paths leave their radiance in a per-path slot and a
-// final kernel adds the slots of each pixel in stratum order, so the accumulator is
+// consecutive strata as independent paths; a step is one closest-hit launch, which also sorts
+// the paths by material type into per-type queues, and one shading launch per material type
+// present in the scene, which evaluates the vertex, applies Russian roulette and appends the
+// survivors to the next ray queue.  In the rolling schedule a step carries bounce 0 of a new
+// batch together with the later bounces of the batches before it; the other schedule runs the
+// bounces of one batch after another.  Work sizes are read from device memory, so steps follow
+// each other without host synchronisation.  Finished paths leave their radiance in a per-path
+// slot and a final kernel adds the slots of each pixel in stratum order, so the accumulator is
 // deterministic and sums in the order the reference does.
 #include <hip/hip_runtime.h>
 
@@ -26,816 +28,7 @@
 #include <vector>
 
 #include "bvh_build.h"
-#include "dev_shade.h"
-#include "dev_walk.h"
-
-using namespace ptd;
-
-// ============================================================================ kernels
-
-struct DevStats {
-    unsigned long long rays_total, paths_total, extend_nonempty;
-    unsigned long long node_tests, tri_tests, sphere_tests, quad_tests;
-    // PT_BOUNDS_CHECK build only: [0] out-of-range references caught, [1] lanes that gave up after too
-    // many passes, [2..7] state of the first such lane
-    unsigned long long bad_refs[8];
-};
-
-struct BatchParams {
-    uint64_t seed_mixed;
-    uint32_t stratum_first;  // first stratum of this batch
-    uint32_t n_strata;       // strata in this batch
-    uint32_t npix;
-    uint32_t n_slots;        // npix * n_strata
-    float bsdf_prob;
-    f3 background;
-};
-// Paths of a batch are numbered pixel-major: slot = pixel * n_strata + (stratum - stratum_first).
-// The 64 lanes of a wave then hold the strata of a few neighbouring pixels — almost the same
-// ray — and a contiguous range of slots is a band of the image with all its strata, which is
-// what the per-XCD split of the queues below relies on for L2 locality.
-__device__ __forceinline__ void slot_to_sample(const BatchParams &bp, uint32_t slot, uint32_t &pixel, uint32_t &stratum) {
-    pixel = slot / bp.n_strata;
-    stratum = bp.stratum_first + (slot - pixel * bp.n_strata);
-}
-
-// Consumer side of a chunked queue with a fixed share per wave: wave w takes the 64-entry
-// pieces w, w + waves, ... of the chunks in use.
-struct PieceWalk {
-    uint32_t piece, n_pieces, step;
-};
-__device__ __forceinline__ PieceWalk piece_walk(uint32_t n_chunks) {
-    return PieceWalk{wave_index(), n_chunks * (QUEUE_CHUNK / 64u), wave_count()};
-}
-
-// Open chunks of the material queues, one set per wave of the workgroup, kept in LDS
-// because their number is only known at run time.  Only the owning wave touches its row.
-__shared__ uint32_t g_shade_push[BLOCK / 64][MAX_QUEUES][2];
-__device__ __forceinline__ void shade_push_init() {
-    const uint32_t l = lane_id();
-    if (l < MAX_QUEUES) {
-        g_shade_push[threadIdx.x / 64u][l][0] = QUEUE_EMPTY;
-        g_shade_push[threadIdx.x / 64u][l][1] = 0u;
-    }
-}
-__device__ __forceinline__ void shade_push_close(const PathState &ps) {
-    for (uint32_t q = 0; q < ps.n_queues; q++) {
-        WavePush w;
-        w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_shade_push[threadIdx.x / 64u][q][0]);
-        w.fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_shade_push[threadIdx.x / 64u][q][1]);
-        wave_push_close(w, ps.shade_queue[q]);
-    }
-}
-
-// Camera::get_ray (src/camera.rs:238-260) for one (pixel, stratum).
-__device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint32_t pixel, uint32_t stratum, f3 &o, f3 &d) {
-    const float u = (float)(pixel % cam.width), v = (float)(pixel / cam.width);
-    const float s_u = (float)(stratum / cam.sqrt_spp), s_v = (float)(stratum % cam.sqrt_spp);
-    float disk_u, disk_v;
-    for (;;) {  // DiskSampler::unit(), src/types/sampler.rs:49-58: drawn even when there is no lens
-        float x = rng.range(-1.0f, 1.0f);
-        float y = rng.range(-1.0f, 1.0f);
-        if (x * x + y * y < 1.0f) {
-            disk_u = x;
-            disk_v = y;
-            break;
-        }
-    }
-    f3 ray_center = cam.center;
-    if (!(cam.defocus_angle <= 0.0f)) ray_center = cam.center + disk_u * cam.disk_u + disk_v * cam.disk_v;
-    const float sx = rng.range(0.0f, 1.0f);  // SquareSampler((0.5, 0.5), 0.5)
-    const float sy = rng.range(0.0f, 1.0f);
-    const float offset_u = (s_u + sx) * cam.inv_sqrt_spp - 0.5f;
-    const float offset_v = (s_v + sy) * cam.inv_sqrt_spp - 0.5f;
-    const f3 pixel_center = cam.pixel00 + (u + offset_u) * cam.pixel_du + (v + offset_v) * cam.pixel_dv;
-    o = ray_center;
-    d = pixel_center - ray_center;
-}
-
-// ROLL: the batch goes to the region starting at slot `base`, whose parameters are recorded for
-// the kernels that meet its paths later, and no queue is written: the closest-hit kernel takes
-// the new paths by their slot numbers.
-template <bool ROLL>
-__global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, BatchParams bp, uint32_t base, DevStats *stats) {
-    const uint32_t n = bp.n_slots;
-    for (uint32_t local = blockIdx.x * BLOCK + threadIdx.x; local < n; local += gridDim.x * BLOCK) {
-        uint32_t pixel, stratum;
-        slot_to_sample(bp, local, pixel, stratum);
-        Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, 0u);
-        f3 o, d;
-        camera_ray(cam, rng, pixel, stratum, o, d);
-        const uint32_t slot = base + local;
-        ps.ray_o[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.counter));
-        ps.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cam.max_depth));
-        ps.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, ps.moving ? path_time(rng.key) : 0.0f);
-        ps.contrib[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!ROLL) ps.ray_queue[0][slot] = slot;
-    }
-    if (blockIdx.x == 0) {
-        if (!ROLL) {
-            const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
-            for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
-            if (threadIdx.x == 0) ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
-        } else if (threadIdx.x == 0) {
-            RegionParams rp{};
-            rp.seed_mixed = bp.seed_mixed;
-            rp.stratum_first = bp.stratum_first;
-            rp.n_strata = bp.n_strata;
-            ps.regions[base / ps.region_cap] = rp;
-        }
-        if (threadIdx.x == 0) {
-            atomicAdd(&stats->paths_total, (unsigned long long)n);
-            atomicAdd(&stats->rays_total, (unsigned long long)n);
-        }
-    }
-}
-
-// Rays only (pt_generate_rays).
-__global__ __launch_bounds__(BLOCK) void k_raygen_only(DevCamera cam, BatchParams bp, float *rays) {
-    for (uint32_t pixel = blockIdx.x * BLOCK + threadIdx.x; pixel < bp.npix; pixel += gridDim.x * BLOCK) {
-        Rng rng;
-        rng.init(bp.seed_mixed, pixel, bp.stratum_first, 0u);
-        f3 o, d;
-        camera_ray(cam, rng, pixel, bp.stratum_first, o, d);
-        float *r = rays + 8 * (size_t)pixel;
-        r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z; r[6] = 0.001f; r[7] = INFINITY;
-    }
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, 64);
-    return v;
-}
-
-// After the closest hit is known: missed paths and paths that hit a primitive without
-// material finish here (src/camera.rs:371, :277-283); the others are appended to the queue
-// of their material type.  Every lane of the wave must call this (inactive lanes with
-// active == false), after shade_push_init() and before shade_push_close().
-__device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, uint32_t parity, f3 background, bool active,
-                                         uint32_t slot, uint32_t code, uint32_t prim) {
-    uint32_t qslot = 0xFFu;
-    if (active) {
-        int32_t mat = -1;
-        if (code != PTD_HIT_MISS) {
-            const uint32_t type = code & 3u;
-            mat = (type == PT_PRIM_TRI) ? sc.tri_mat[prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[prim] : sc.quad_mat[prim]);
-        }
-        // without a surface to shade the path ends here, unless the scene has participating media: then it
-        // may still scatter on its way out, and shade_vertex<PTD_MAT_MEDIUM> decides (medium_queue is 0xFF otherwise)
-        qslot = mat >= 0 ? sc.mat_queue[mat] : sc.medium_queue;
-        if (qslot == 0xFFu) {
-            if (!ps.nee) {
-                const float4 b = ps.beta[slot];
-                const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
-                ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
-            } else if (code == PTD_HIT_MISS) {  // contrib already holds the light samples of the earlier vertices
-                const float4 b = ps.beta[slot], c = ps.contrib[slot];
-                ps.contrib[slot] = make_float4(c.x + b.x * background.x, c.y + b.y * background.y, c.z + b.z * background.z, 0.0f);
-            }
-        }
-    }
-    // one pass per material queue that some lane of this wave needs
-    unsigned long long todo = __ballot(qslot != 0xFFu);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)qslot, leader);
-        const bool mine = qslot == q;
-        uint32_t *state = g_shade_push[threadIdx.x / 64u][q];
-        WavePush w;
-        w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[0]);
-        w.fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[1]);
-        wave_push(w, mine, slot, ps.shade_queue[q], &ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE]);
-        if (lane_id() == 0u) {
-            state[0] = w.chunk;
-            state[1] = w.fill;
-        }
-        todo &= ~__ballot(mine);
-    }
-}
-
-// What every closest-hit kernel does first: clear the control words the shade kernels of
-// this bounce will fill, and count the launch.
-__device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bounce, uint32_t n_chunks, DevStats *stats) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint32_t parity = bounce & 1u;
-        ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        if (n_chunks) atomicAdd(&stats->extend_nonempty, 1ull);
-    }
-}
-
-__device__ __forceinline__ void flush_counters(bool count, const TravCounters &tc, DevStats *stats) {
-    if (!count) return;
-    const uint32_t a = wave_sum(tc.nodes), b = wave_sum(tc.tris), c = wave_sum(tc.spheres), d = wave_sum(tc.quads);
-    if (lane_id() == 0) {
-        if (a) atomicAdd(&stats->node_tests, (unsigned long long)a);
-        if (b) atomicAdd(&stats->tri_tests, (unsigned long long)b);
-        if (c) atomicAdd(&stats->sphere_tests, (unsigned long long)c);
-        if (d) atomicAdd(&stats->quad_tests, (unsigned long long)d);
-    }
-}
-
-// Closest hit among the world's triangles, spheres and quads for every ray of the current
-// queue (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
-// CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
-template <bool COUNT, bool CLASSIFY>
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    extend_prologue(ps, bounce, n_chunks, stats);
-    if (CLASSIFY) shade_push_init();
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    TravCounters tc{0, 0, 0, 0};
-    const uint32_t *queue = ps.ray_queue[parity];
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        const bool active = slot != QUEUE_EMPTY;
-        HitState h;
-        h.code = PTD_HIT_MISS;
-        h.prim = 0;
-        if (active) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            hit_world_prims(sc, r, h, st, tc);
-            ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-            ps.hit2[slot] = h.code;
-        }
-        if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim);
-    }
-    if (CLASSIFY) shade_push_close(ps);
-    flush_counters(COUNT, tc, stats);
-}
-
-// The whole of PrimitiveBuffer::hit with rays drawn by the waves as their lanes fall idle
-// (dev_walk.h); this is the form used for rendering whenever the scene's leaves fit the
-// 64-byte node layout.  INSTANCES: the world has an instance buffer.
-#ifdef PT_WALK_WAVES
-#define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
-#else
-#define WALK_OCCUPANCY
-#endif
-// The work is the current ray queue followed by the `n_new` paths in slots new_base.. that a
-// k_raygen<true> has just started (no queue entries exist for those).
-// MOVING: the scene has moving spheres (pts_moving_sphere): a finished ray is tested against them, where
-// they are at its path's time, before it is classified.
-template <bool INSTANCES, bool MOVING>
-__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, uint32_t new_base,
-                                                                      uint32_t n_new, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    extend_prologue(ps, bounce, n_chunks + n_new, stats);
-    const uint32_t queued = n_chunks * QUEUE_CHUNK;
-    const uint32_t n_pieces = queued / 64u + (n_new + 63u) / 64u;
-    if (n_pieces == 0u) return;
-    shade_push_init();
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    const uint32_t *queue = ps.ray_queue[parity];
-    walk_world<INSTANCES>(
-        sc, n_pieces, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
-        [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            if (i < queued) {
-                slot = queue[i];
-                if (slot == QUEUE_EMPTY) return false;
-            } else {
-                if (i - queued >= n_new) return false;
-                slot = new_base + (i - queued);
-            }
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            return true;
-        },
-        [&](uint32_t slot, f3 &o, f3 &d) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            o = mk3(ro.x, ro.y, ro.z);
-            d = mk3(rd.x, rd.y, rd.z);
-        },
-        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
-            if constexpr (MOVING) {
-                TravRay r2 = r;
-                HitState h2 = h;
-                if (done) {
-                    const float time = ps.beta[slot].w;
-                    for (uint32_t k = 0; k < sc.n_moving; k++) {
-                        const uint32_t g = sc.n_static_spheres + k;
-                        const float4 sp = sc.spheres[g], dl = sc.moving_delta[k];
-                        const f3 c = mk3(sp.x, sp.y, sp.z) + time * mk3(dl.x, dl.y, dl.z);
-                        hit_sphere(make_float4(c.x, c.y, c.z, sp.w), g, r2, h2, 0u);
-                    }
-                    ps.hit[slot] = make_float4(r2.t_max, h2.u, h2.v, __uint_as_float(h2.prim));
-                    ps.hit2[slot] = h2.code;
-                }
-                classify(sc, ps, parity, background, done, slot, h2.code, h2.prim);
-            } else {
-                if (done) {
-                    ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-                    ps.hit2[slot] = h.code;
-                }
-                classify(sc, ps, parity, background, done, slot, h.code, h.prim);
-            }
-        });
-    shade_push_close(ps);
-}
-
-// The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
-// continuing from the hit and t_max the first kernel left; then classification.
-template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    shade_push_init();
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    TravCounters tc{0, 0, 0, 0};
-    const uint32_t *queue = ps.ray_queue[parity];
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        const bool active = slot != QUEUE_EMPTY;
-        HitState h;
-        h.code = PTD_HIT_MISS;
-        h.prim = 0;
-        if (active) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot], h4 = ps.hit[slot];
-            h.u = h4.y;
-            h.v = h4.z;
-            h.prim = __float_as_uint(h4.w);
-            h.code = ps.hit2[slot];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, h4.x);
-            const uint32_t before = h.code;
-            const float t_before = r.t_max;
-            hit_world_insts(sc, r, h, st, tc);
-            if (h.code != before || r.t_max != t_before || h.prim != __float_as_uint(h4.w)) {
-                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-                ps.hit2[slot] = h.code;
-            }
-        }
-        classify(sc, ps, parity, background, active, slot, h.code, h.prim);
-    }
-    shade_push_close(ps);
-    flush_counters(COUNT, tc, stats);
-}
-
-// The surface part of shade_vertex below.
-template <int MT, bool NEE>
-__device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow,
-                                              f3 ro, f3 rd, float4 h4, float4 b4, uint32_t code, f3 beta, uint32_t depth, uint32_t rng_counter) {
-    const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code, NEE ? 0.0f : b4.w);
-    const DevMaterial m = sc.mats[s.material];
-    shadow = false;
-    if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
-        // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
-        f3 e = mk3(0.0f, 0.0f, 0.0f);
-        if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v, s.p);
-        if constexpr (NEE) {
-            float w = 1.0f;
-            if (b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true>(sc, ro, rd));
-            const float4 c = ps.contrib[slot];
-            const f3 add = cmul(beta, e) * w;
-            ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
-        } else {
-            ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
-        }
-    } else {
-        uint32_t pixel, stratum;
-        slot_to_sample(bp, local, pixel, stratum);
-        Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, rng_counter);
-        const Onb surface = make_onb(s.normal);
-        const f3 w_out = -normalize(to_local(surface, rd));
-        f3 w_in_world;
-        bool go_on = true;
-        float drawn_with = 0.0f;  // NEE: density of the ray that leaves this vertex, 0 = specular
-        if constexpr (MT == PTS_MAT_METAL || MT == PTS_MAT_DIELECTRIC) {
-            // purely specular: no pdf, no roulette (camera.rs:298-313)
-            const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
-            const f3 attenuation = mat_eval<MT>(sc, m, w_out, w_in, s);
-            w_in_world = to_world(surface, w_in);
-            beta = cmul(beta, attenuation);
-        } else if constexpr (NEE && (MT == PTS_MAT_LAMBERTIAN || MT == PTS_MAT_DISNEY_DIFFUSE || MT == PTS_MAT_DISNEY_SHEEN)) {
-            if (sc.n_light_total != 0u) {
-                const f3 ls = light_sample<true>(sc, rng, s.p);
-                const float lp = light_pdf<true>(sc, s.p, ls);
-                if (lp > 0.0f && lp < INFINITY) {
-                    const f3 wl = normalize(to_local(surface, ls));
-                    const float sp = mat_pdf<MT>(m, w_out, wl, s);
-                    if (sp > 0.0f) {
-                        const f3 f = mat_eval<MT>(sc, m, w_out, wl, s) * fabsf(wl.y);
-                        const f3 c = cmul(beta, f) / (lp + sp);
-                        ps.hit[slot] = make_float4(ls.x, ls.y, ls.z, 0.0f);
-                        ps.shadow_c[slot] = make_float4(c.x, c.y, c.z, 0.0f);
-                        shadow = true;
-                    }
-                }
-            }
-            const f3 w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
-            w_in_world = to_world(surface, w_in);
-            const float sp = mat_pdf<MT>(m, w_out, w_in, s);
-            const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
-            const float cosv = fabsf(w_in.y);
-            const f3 throughput = (bsdf * cosv) / sp;
-            const float weight = 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
-            if (weight != weight || rng.gen_bool(weight)) {
-                go_on = false;
-            } else {
-                beta = cmul(beta, throughput / (1.0f - weight));
-                drawn_with = sp;
-            }
-        } else {
-            // mixture of BSDF sampling and light sampling (camera.rs:317-357)
-            f3 w_in;
-            bool is_bsdf;
-            if (rng.gen_bool(bp.bsdf_prob)) {
-                w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
-                is_bsdf = true;
-                w_in_world = to_world(surface, w_in);
-            } else {
-                const f3 ls = light_sample(sc, rng, s.p);
-                w_in = normalize(to_local(surface, ls));
-                is_bsdf = false;
-                w_in_world = ls;
-            }
-            if (!is_bsdf) depth = 2u;
-            const float scatter_pdf = mat_pdf<MT>(m, w_out, w_in, s);
-            // with probability 1 for BSDF sampling the light term is a product with zero: 0, or NaN
-            const float l_pdf = bp.bsdf_prob == 1.0f ? light_pdf_times_zero(sc, s.p, w_in_world) : light_pdf(sc, s.p, w_in_world);
-            const float pdf = bp.bsdf_prob * scatter_pdf + (1.0f - bp.bsdf_prob) * l_pdf;
-            const f3 bsdf = mat_eval<MT>(sc, m, w_out, w_in, s);
-            const float cosv = fabsf(w_in.y);
-            const f3 throughput = (bsdf * cosv) / pdf;
-            const float weight = !is_bsdf ? 0.0f : 1.0f - rclamp(rmax(throughput.z, rmax(throughput.y, throughput.x)), 0.0f, 1.0f);
-            if (weight != weight || rng.gen_bool(weight)) {
-                go_on = false;  // returns Color::gray(0): contrib stays zero
-            } else {
-                beta = cmul(beta, throughput / (1.0f - weight));
-            }
-        }
-        if (go_on) {
-            depth -= 1u;
-            if (depth == 0u) {
-                // the next ray_color call returns zeros without tracing (camera.rs:271-273)
-                if constexpr (!NEE) ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
-            } else {
-                ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
-                ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
-                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, NEE ? drawn_with : b4.w);  // w: the path's time unless NEE
-                return true;
-            }
-        }
-        if (NEE && shadow) ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, 0.0f);  // the shadow ray still starts here
-    }
-    return false;
-}
-
-// One path vertex: the body of Camera::ray_color after the hit (src/camera.rs:286-369), in
-// multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
-// type MT; `local` is its number within its batch.  Returns true when the path goes on: its
-// next ray is then in ps.ray_o / ps.ray_d.
-//
-// NEE selects the integrator that is not in the reference (PT_OPT_INTEGRATOR = 1): next-event
-// estimation with one light sample per vertex and the balance heuristic, at the vertices whose
-// material has a scattering_pdf that is the density of its scatter (Lambertian, DisneyDiffuse,
-// DisneySheen: checked numerically in tests/test_material_pdfs.py; for the other Disney lobes of
-// the reference it is not, so no combination of the two samplers can reproduce what the
-// reference's estimator converges to, and those vertices are handled exactly as the reference
-// does, with BSDF sampling alone).  At a vertex with light sampling a direction is drawn with
-// LightBuffer::sample; when its density lp is positive and finite and the BSDF sampler could
-// have produced it (sp > 0), shadow = true and the path leaves (direction, beta * f * |cos| /
-// (lp + sp)) in ps.hit / ps.shadow_c for the shadow-ray kernel.  The path itself continues by
-// BSDF sampling with the reference's roulette; an emitter found that way counts with weight
-// sp' / (sp' + lp'), and fully after the camera or a vertex without light sampling.  Radiance is
-// added to ps.contrib as it is found; paths that end without finding any add nothing.
-template <int MT, bool NEE, bool MEDIA = false>
-__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow) {
-    const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
-    const uint32_t code = ps.hit2[slot];
-    const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
-    f3 beta = mk3(b4.x, b4.y, b4.z);
-    uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
-    shadow = false;
-    uint32_t rng_counter = __float_as_uint(ro4.w);
-    if constexpr (MT == PTD_MAT_MEDIUM || MEDIA) {
-        // participating media (not in the reference): the ray may scatter before it reaches what it hit
-        uint32_t pixel, stratum;
-        slot_to_sample(bp, local, pixel, stratum);
-        Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, rng_counter);
-        const bool missed = MT == PTD_MAT_MEDIUM && code == PTD_HIT_MISS;
-        float t_event;
-        uint32_t which = 0u;
-        if (medium_event(sc, rng, ro, rd, missed ? INFINITY : h4.x, t_event, which)) {
-            const f3 p = ro + t_event * rd;
-            const f3 albedo = tex_value(sc, sc.media[which].texture, 0.0f, 0.0f, p);
-            const f3 dir = medium_direction(rng);
-            beta = cmul(beta, albedo);
-            depth -= 1u;
-            if (depth == 0u) {
-                ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
-                return false;
-            }
-            ps.ray_o[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.counter));
-            ps.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth));
-            ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, b4.w);
-            return true;
-        }
-        rng_counter = rng.counter;
-        if constexpr (MT == PTD_MAT_MEDIUM) {  // nothing to shade: src/camera.rs:371, :277-283
-            const f3 l = missed ? bp.background : mk3(0.0f, 0.0f, 0.0f);
-            ps.contrib[slot] = make_float4(beta.x * l.x, beta.y * l.y, beta.z * l.z, 0.0f);
-            return false;
-        }
-    }
-    if constexpr (MT == PTD_MAT_MEDIUM) return false;
-    else return shade_surface<MT, NEE>(sc, ps, bp, slot, local, shadow, ro, rd, h4, b4, code, beta, depth, rng_counter);
-}
-
-// shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
-// ROLL: the queue mixes batches, `bp` holds what they have in common and the rest comes from the
-// path's region.
-// MODE: 0 = the reference's estimator, 1 = next-event estimation, 2 = the reference's estimator in a scene with
-// participating media.
-template <int MT, bool ROLL, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
-    constexpr bool NEE = MODE == 1, MEDIA = MODE == 2;
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
-    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-    const uint32_t *queue = ps.shade_queue[q];
-    WavePush out, shadows;
-    out.init();
-    shadows.init();
-    uint32_t survivors = 0u;  // rays this launch starts: next-bounce rays and shadow rays
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        bool alive = false, shadow = false;
-        if (slot != QUEUE_EMPTY) {
-            if constexpr (ROLL) {
-                const uint32_t region = slot / ps.region_cap;
-                const RegionParams rp = ps.regions[region];
-                BatchParams mine = bp;
-                mine.seed_mixed = rp.seed_mixed;
-                mine.stratum_first = rp.stratum_first;
-                mine.n_strata = rp.n_strata;
-                alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, mine, slot, slot - region * ps.region_cap, shadow);
-            } else {
-                alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, bp, slot, slot, shadow);
-            }
-        }
-        if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
-            survivors += (uint32_t)__popcll(__ballot(alive));
-            wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
-            if constexpr (NEE) {
-                survivors += (uint32_t)__popcll(__ballot(shadow));
-                wave_push(shadows, shadow, slot, ps.shadow_queue, &ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE]);
-            }
-        }
-    }
-    if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
-        wave_push_close(out, ps.ray_queue[parity ^ 1u]);
-        if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
-        if (survivors && lane_id() == 0u) {
-            atomicAdd(&stats->rays_total, (unsigned long long)survivors);
-            if (!ROLL && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
-        }
-    }
-}
-
-// Shadow rays of one step (next-event estimation): closest hit along each, and where that is an
-// emitter, its radiance times the factor the vertex left behind goes to the path.
-template <bool INSTANCES>
-__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the shading of the next step
-        ps.ctl[(CTL_SHADOW_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        ps.ctl[(CTL_SHADOW_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-    }
-    if (n_chunks == 0u) return;
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    const uint32_t *queue = ps.shadow_queue;
-    walk_world<INSTANCES>(
-        sc, n_chunks * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_SHADOW_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
-        [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            slot = queue[i];
-            if (slot == QUEUE_EMPTY) return false;
-            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
-            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            return true;
-        },
-        [&](uint32_t slot, f3 &o, f3 &d) {
-            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
-            o = mk3(ro.x, ro.y, ro.z);
-            d = mk3(rd.x, rd.y, rd.z);
-        },
-        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
-            if (!done || h.code == PTD_HIT_MISS) return;
-            const uint32_t type = h.code & 3u;
-            const int32_t mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
-            if (mat < 0 || sc.mats[mat].type != PTS_MAT_DIFFUSE_LIGHT) return;
-            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
-            const Surf s = make_surf(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), r.t_max, h.u, h.v, h.prim, h.code);
-            if (!s.front_face) return;
-            const f3 e = tex_value(sc, sc.mats[mat].texture, s.u, s.v, s.p);
-            const float4 f = ps.shadow_c[slot], c = ps.contrib[slot];
-            const f3 add = cmul(mk3(f.x, f.y, f.z), e);
-            ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
-        });
-}
-
-// Everything that is left of a batch from bounce `bounce` on, in one launch: each lane takes a
-// path of the ray queue and alternates closest hit (the reference-order loop) and shade_vertex
-// until the path ends.  Used where a batch has thinned to a few thousand paths: per-bounce
-// launches then cost more in launch latency than the work they carry, and this also covers
-// however many bounces remain without the host having to know.  The functions are the ones the
-// per-bounce kernels call, so every path gets the same arithmetic.
-__global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, f3 background, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    TravCounters tc{0, 0, 0, 0};
-    const uint32_t *queue = ps.ray_queue[parity];
-    const bool insts = sc.world.insts.prim_count != 0u;
-    uint32_t traced = 0u;  // rays beyond the ones the queue held (those are already counted)
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        if (slot == QUEUE_EMPTY) continue;
-        for (;;) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            HitState h;
-            hit_world_prims(sc, r, h, st, tc);
-            if (insts) hit_world_insts(sc, r, h, st, tc);
-            int32_t mat = -1;
-            if (h.code != PTD_HIT_MISS) {
-                const uint32_t type = h.code & 3u;
-                mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
-            }
-            if (mat < 0) {  // src/camera.rs:371, :277-283
-                const float4 b = ps.beta[slot];
-                const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
-                ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
-                break;
-            }
-            ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-            ps.hit2[slot] = h.code;
-            bool alive = false, shadow;
-            switch (sc.mats[mat].type) {
-                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN, false>(sc, ps, bp, slot, slot, shadow); break;
-                default: break;
-            }
-            if (!alive) break;
-            traced++;
-        }
-    }
-    if (traced) atomicAdd(&stats->rays_total, (unsigned long long)traced);
-}
-
-// `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).
-__global__ __launch_bounds__(BLOCK) void k_accumulate(const float4 *contrib, float *accum, uint32_t npix, uint32_t n_strata) {
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
-        float r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2];
-        for (uint32_t k = 0; k < n_strata; k++) {
-            const float4 c = contrib[(size_t)p * n_strata + k];
-            if (c.x != c.x || c.y != c.y || c.z != c.z) continue;
-            r += c.x;
-            g += c.y;
-            b += c.z;
-        }
-        accum[3 * p] = r;
-        accum[3 * p + 1] = g;
-        accum[3 * p + 2] = b;
-    }
-}
-
-// ColorOps::to_rgb (src/types/color.rs:36-42, :68-78) of sum / samples (camera.rs:223-225).
-__device__ __forceinline__ float linear_to_gamma(float c) {
-    if (c < 0.0031308f) return 12.92f * c;
-    return 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
-}
-__global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, uint8_t *rgb, uint32_t npix, float samples) {
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
-        for (int c = 0; c < 3; c++) {
-            const float lin = accum[3 * p + c] / samples;
-            uint32_t v = f2u32_sat(255.999f * linear_to_gamma(lin));
-            rgb[3 * p + c] = (uint8_t)(v > 255u ? 255u : v);
-        }
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathState ps, uint32_t n) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float *r = rays + 8 * (size_t)i;
-        ps.ray_o[i] = make_float4(r[0], r[1], r[2], r[6]);
-        ps.ray_d[i] = make_float4(r[3], r[4], r[5], r[7]);
-        ps.ray_queue[0][i] = i;
-    }
-    const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
-    if (blockIdx.x == 0) {
-        for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
-        if (threadIdx.x == 0) {
-            ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
-            ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE] = 0u;
-        }
-    }
-}
-
-// Closest hit for caller-supplied rays with their own [t_min, t_max]: the same two parts.
-__global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint32_t n) {
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    TravCounters tc{0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
-        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
-        HitState h;
-        hit_world_prims(sc, r, h, st, tc);
-        ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-        ps.hit2[i] = h.code;
-    }
-}
-template <bool INSTANCES>
-__global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps, uint32_t n, DevStats *stats) {
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    walk_world<INSTANCES>(
-        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
-        [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            slot = ps.ray_queue[0][i];
-            if (slot == QUEUE_EMPTY) return false;
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
-            return true;
-        },
-        [&](uint32_t slot, f3 &o, f3 &d) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            o = mk3(ro.x, ro.y, ro.z);
-            d = mk3(rd.x, rd.y, rd.z);
-        },
-        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
-            if (done) {
-                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-                ps.hit2[slot] = h.code;
-            }
-        });
-}
-__global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps, uint32_t n) {
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    TravCounters tc{0, 0, 0, 0};
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i], h4 = ps.hit[i];
-        HitState h;
-        h.u = h4.y;
-        h.v = h4.z;
-        h.prim = __float_as_uint(h4.w);
-        h.code = ps.hit2[i];
-        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, h4.x);
-        hit_world_insts(sc, r, h, st, tc);
-        ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-        ps.hit2[i] = h.code;
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_trace_out(DevScene sc, PathState ps, uint32_t n, pt_hit *out) {
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float4 h4 = ps.hit[i];
-        const uint32_t code = ps.hit2[i], prim = __float_as_uint(h4.w);
-        pt_hit o;
-        o.t = h4.x;
-        o.u = h4.y;
-        o.v = h4.z;
-        if (code == PTD_HIT_MISS) {
-            o.prim_type = -1;
-            o.prim_id = -1;
-            o.inst_id = -1;
-            o.u = o.v = 0.0f;
-        } else {
-            const uint32_t type = code & 3u, inst1 = code >> 2;
-            o.prim_type = (int32_t)type;
-            o.inst_id = (int32_t)inst1 - 1;
-            const DevSet *set = &sc.sets[0];
-            if (inst1) set = &sc.sets[__float_as_uint(sc.insts[7 * (size_t)(sc.world.insts.prim_first + inst1 - 1u) + 6].x)];
-            const uint32_t first = (type == PT_PRIM_TRI) ? set->tris.prim_first : ((type == PT_PRIM_SPHERE) ? set->spheres.prim_first : set->quads.prim_first);
-            o.prim_id = (int32_t)(prim - first);
-        }
-        out[i] = o;
-    }
-}
+#include "dev_kernels.h"
 
 // ============================================================================ host side
 
