@@ -27,11 +27,13 @@ B_NODE, B_TRI, B_SPHERE, B_QUAD, B_RAY_IO = 32, 36, 16, 64, 32 + 16
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(src, budget_s: float = 12.0):
+def cpu_baseline(src, budget_s: float = 12.0, bsdf_probability: float = 1.0):
     """The CPU restatement of the reference renderer on this host's cores, bounded sample."""
     from oracle.pyoracle import OracleScene
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
     o = OracleScene(src)
+    if bsdf_probability != 1.0:
+        o.set_bsdf_probability(bsdf_probability)
     t0 = time.perf_counter()
     rays = 0
     strata = 0
@@ -65,6 +67,8 @@ def main():
                     help="paths started per launch of the rolling schedule (0: one batch at a time per pipe; -1: library default)")
     ap.add_argument("--integrator", default="reference", choices=["reference", "nee"],
                     help="nee: next-event estimation with shadow rays (not in the reference); no counted pass, so no roofline figure")
+    ap.add_argument("--bsdf-probability", type=float, default=1.0,
+                    help="BSDF_SAMPLE_PROBABILITY of the reference's mixture sampler (src/camera.rs:317); below 1 some rays are aimed at lights")
     ap.add_argument("--extensions", action="store_true", help="next_week_like with its noise texture, media and moving sphere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -81,7 +85,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -113,6 +117,8 @@ def main():
         r.set_option(PT_OPT_ROLLING, args.rolling)
     if args.integrator == "nee":
         r.set_option(PT_OPT_INTEGRATOR, 1)
+    if args.bsdf_probability != 1.0:
+        r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, args.bsdf_probability)
     total_strata = r.sqrt_spp * r.sqrt_spp
     lo, hi = stratum_ranges(total_strata, world)[rank]
     S = min(S, hi - lo)
@@ -206,7 +212,7 @@ def main():
                                    + (" (procedural stand-in for mitsuba_smooth.obj, Disney + Lambertian + emitter)" if args.scene == "knob" else "")
                                    + f", {S} full-frame strata per step per GPU",
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce",
-                       "integrator": args.integrator,
+                       "integrator": args.integrator, "bsdf_sample_probability": args.bsdf_probability,
                        "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
                                     "library default" if args.rolling < 0 else "one batch at a time per pipe")},
             "roofline": {"bound": "hbm", "kernel": "k_extend_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -220,7 +226,7 @@ def main():
             "image_mean": float(img.mean()),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(src, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(src, args.cpu_budget, args.bsdf_probability)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

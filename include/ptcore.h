@@ -228,6 +228,13 @@ int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *ra
 /* PrimitiveBuffer::hit for n caller-supplied rays: rays[n][8] as above, out[n] (host memory). */
 int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out);
 
+/* LightBuffer::pdf (src/objects.rs:259-278) for n caller-supplied rays, of which only origin and
+ * direction count: the sum of every light's pdf for the ray divided by the number of lights, out[n]
+ * (host memory).  tris_by_solid_angle = 0 is the reference's Triangle::pdf, 1 / area
+ * (src/objects/tri_mesh.rs:252-261); 1 converts it to a density over directions as
+ * PT_OPT_INTEGRATOR = 1 uses it. */
+int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_solid_angle, float *out);
+
 /* Accumulator: W*H*3 f32 sums, row-major (i = u + v*W, src/camera.rs:202-205), and the pass count. */
 int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples);
 /* (sum / n_samples).to_rgb() per pixel (src/camera.rs:221-226, src/types/color.rs:68-78). */

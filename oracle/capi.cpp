@@ -309,6 +309,15 @@ void pto_texture_value(const pto_scene *s, int32_t tex, float u, float v, float 
 float pto_light_pdf(const pto_scene *s, const float *origin, const float *dir) {
     return s->sc->lights.pdf(Ray::make(v3(origin[0], origin[1], origin[2]), v3(dir[0], dir[1], dir[2])));
 }
+// LightBuffer::pdf (src/objects.rs:259-278) for n rays, rays[i][8] = origin, direction, (unused) t_min, t_max;
+// solid_angle_tris selects the variant the next-event estimator uses
+void pto_light_pdfs(const pto_scene *s, const float *rays, uint64_t n, int solid_angle_tris, float *out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float *r = rays + 8 * i;
+        const Ray ray = Ray::make(v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]));
+        out[i] = solid_angle_tris ? s->sc->lights.pdf_nee(ray) : s->sc->lights.pdf(ray);
+    }
+}
 // raw generator output, for checking the device generator against this one
 void pto_rng_draws(uint64_t seed, uint32_t pixel, uint32_t stratum, uint32_t n, uint64_t *out) {
     Rng r = Rng::for_sample(seed, pixel, stratum);

@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
         L.pto_texture_value.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]
         L.pto_light_pdf.restype = C.c_float
         L.pto_light_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pto_light_pdfs.restype = None
+        L.pto_light_pdfs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
         L.pto_rng_draws.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
@@ -206,6 +208,13 @@ class OracleScene:
 
     def light_pdf(self, origin, direction) -> float:
         return lib().pto_light_pdf(self.h, _p(_f3(origin)), _p(_f3(direction)))
+
+    def light_pdfs(self, rays: np.ndarray, solid_angle_tris: bool = False) -> np.ndarray:
+        """LightBuffer::pdf for rays[n][8] (origin, direction, two unused floats)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        out = np.zeros(rays.shape[0], np.float32)
+        lib().pto_light_pdfs(self.h, _p(rays), rays.shape[0], int(solid_angle_tris), _p(out))
+        return out
 
 
 def refract(w_o, n, eta):

@@ -815,3 +815,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace_out(DevScene sc, PathState ps, 
     }
 }
 
+// LightBuffer::pdf for caller-supplied rays (origin and direction of rays[i][8]).
+__global__ __launch_bounds__(BLOCK) void k_light_pdf(DevScene sc, const float *rays, uint32_t n, int tris_by_solid_angle, float *out) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float *r = rays + 8 * (size_t)i;
+        const f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+        out[i] = tris_by_solid_angle ? light_pdf<true>(sc, o, d) : light_pdf<false>(sc, o, d);
+    }
+}

@@ -63,6 +63,8 @@ struct DevScene {
     const float4 *moving_delta; // moving spheres (pts_moving_sphere): centre at time 1 minus centre at time 0, for the
                                 // last n_moving entries of `spheres`, which no set and no BVH refers to
     const uint32_t *tri_order;  // [n_tris] position at upload of the triangle now at each position
+    const float4 *light_boxes;  // [2 * (light triangles + spheres + quads)] lower, upper corner of a box around each
+                                // light in LightBuffer order, already widened by the light's own share of light_pad
     DevSet world;   // sets[0]
     DevSet lights;  // sets[1]
     uint32_t n_materials;
@@ -71,6 +73,8 @@ struct DevScene {
     uint32_t n_media;
     uint32_t n_moving, n_static_spheres;
     uint32_t medium_queue;   // with media: the shade queue that rays without a surface to shade go to
+    float light_pad_flat, light_pad_sphere;  // light_boxes are widened by this * (largest |coordinate| of the ray origin)
+                                             // when tested: triangles and quads, spheres
     uint32_t n_wide, n_tris, n_spheres, n_quads, n_insts, n_sets;  // array lengths (bounds-checking build)
 };
 

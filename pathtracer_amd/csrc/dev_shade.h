@@ -586,23 +586,31 @@ __device__ inline f3 medium_direction(Rng &rng) {
 }
 
 // ---------------------------------------------------------------- lights (src/objects.rs:235-278)
-// pdf of one light for a ray: the primitive's `hit` on a copy of the ray, then its formula.
+// LightBuffer::pdf: the sum over every light of its pdf for the ray, divided by the number of lights
+// (src/objects.rs:259-278).  A light's pdf is the primitive's `hit` on a copy of the ray, then its
+// formula; a light the ray misses adds 0, which leaves the f32 sum as it is.  So the sum over the
+// lights that are hit, in the reference's order (triangles, spheres, quads), has the same bits as the
+// sum over all of them.  Each light has a box in sc.light_boxes, wide enough that a ray which passes
+// outside it is rejected by the exact test as well; the first loop tests up to 32 boxes with the same
+// control flow in every lane and notes the survivors in a bit mask, the second runs the exact tests of
+// those, lowest index first.
+//
 // Triangle::pdf of the reference is 1 / area, a density over the triangle rather than over
 // directions (spheres and quads report a solid-angle density).  TRIS_BY_SOLID_ANGLE converts it,
 // distance^2 / (cosine * area) as Quad::pdf does; only the next-event estimator, which is not
 // part of the reference and needs the density Triangle::sample really has, asks for that.
-template <bool TRIS_BY_SOLID_ANGLE = false>
-__device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
-    float pdf = 0.0f;
-    TravCounters tc{0, 0, 0, 0};
+template <bool TRIS_BY_SOLID_ANGLE>
+__device__ inline float light_term(const DevScene &sc, uint32_t i, f3 o, f3 d) {
     const DevSet &L = sc.lights;
-    for (uint32_t i = 0; i < L.tris.prim_count; i++) {  // Triangle::pdf, tri_mesh.rs:252-261
+    const uint32_t nt = L.tris.prim_count, ns = L.spheres.prim_count;
+    TravCounters tc{0, 0, 0, 0};
+    TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
+    HitState h;
+    h.code = PTD_HIT_MISS;
+    float term = 0.0f;
+    if (i < nt) {  // Triangle::pdf, tri_mesh.rs:252-261
         const uint32_t g = L.tris.prim_first + i;
-        TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
-        HitState h;
-        h.code = PTD_HIT_MISS;
         hit_prim<PT_PRIM_TRI>(sc, g, r, h, 0u, tc);
-        float term = 0.0f;
         if (h.code != PTD_HIT_MISS) {
             const float4 a = sc.tri_hot[3 * g], b = sc.tri_hot[3 * g + 1], c = sc.tri_hot[3 * g + 2];
             const f3 n = cross(mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x));
@@ -615,30 +623,18 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
                 term = 2.0f / norm(n);
             }
         }
-        pdf += term;
-    }
-    for (uint32_t i = 0; i < L.spheres.prim_count; i++) {  // Sphere::pdf, sphere.rs:109-120
-        const uint32_t g = L.spheres.prim_first + i;
-        TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
-        HitState h;
-        h.code = PTD_HIT_MISS;
+    } else if (i < nt + ns) {  // Sphere::pdf, sphere.rs:109-120
+        const uint32_t g = L.spheres.prim_first + (i - nt);
         hit_prim<PT_PRIM_SPHERE>(sc, g, r, h, 0u, tc);
-        float term = 0.0f;
         if (h.code != PTD_HIT_MISS) {
             const float4 s = sc.spheres[g];
             float cos_theta_max = sqrtf(1.0f - s.w * s.w / norm_squared(mk3(s.x, s.y, s.z) - o));
             float solid_angle = 2.0f * PTD_PI * (1.0f - cos_theta_max);
             term = 1.0f / solid_angle;
         }
-        pdf += term;
-    }
-    for (uint32_t i = 0; i < L.quads.prim_count; i++) {  // Quad::pdf, quad_mesh.rs:165-175
-        const uint32_t g = L.quads.prim_first + i;
-        TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
-        HitState h;
-        h.code = PTD_HIT_MISS;
+    } else {  // Quad::pdf, quad_mesh.rs:165-175
+        const uint32_t g = L.quads.prim_first + (i - nt - ns);
         hit_prim<PT_PRIM_QUAD>(sc, g, r, h, 0u, tc);
-        float term = 0.0f;
         if (h.code != PTD_HIT_MISS) {
             const float4 q2 = sc.quads[4 * (size_t)g + 2];
             f3 qn = mk3(q2.y, q2.z, q2.w);
@@ -647,9 +643,57 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
             float cosine = fabsf(dot(d, qn)) / norm(d);
             term = distance_squared / (cosine * sc.quad_area[g]);
         }
-        pdf += term;
     }
-    for (uint32_t i = 0; i < L.insts.prim_count; i++) pdf += 0.0f;  // Hittable::pdf default (:97-99)
+    return term;
+}
+typedef float light_box_t __attribute__((ext_vector_type(8)));  // lower corner, unused, upper corner, unused
+template <bool TRIS_BY_SOLID_ANGLE = false>
+__device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
+    const DevSet &L = sc.lights;
+    // The boxes are read-only for as long as the scene lives and every lane reads the same one: through
+    // the constant address space they come in over the scalar unit, one load per box for the wave.
+    const __attribute__((address_space(4))) light_box_t *boxes = (const __attribute__((address_space(4))) light_box_t *)sc.light_boxes;
+    const float o_max = rmax(fabsf(o.x), rmax(fabsf(o.y), fabsf(o.z)));
+    // a component of the direction that is zero (or next to it) counts as +-1e-25: the ray then leaves a slab
+    // it starts in only far beyond anything else, and no product below is 0 * inf
+    auto inverse = [](float x) { return fabsf(x) > 1.0e-25f ? 1.0f / x : copysignf(1.0e25f, x); };
+    const f3 inv = mk3(inverse(d.x), inverse(d.y), inverse(d.z));
+    // Only rays of ordinary size are tested against the boxes.  Sphere::hit divides by |d|^2: when that is
+    // zero, or anything is NaN, its root is NaN, which passes the range check, so such a ray "hits" every
+    // sphere wherever it is; and a huge origin or direction would overflow the products below.
+    const float dd = norm_squared(d);
+    const bool ordinary = dd > 1.0e-30f && dd < 1.0e30f && o_max < 1.0e10f;
+    float pdf = 0.0f;
+    uint32_t first = 0;
+#pragma nounroll
+    for (int kind = 0; kind < 3; kind++) {  // triangles, spheres, quads; instances: Hittable::pdf default, 0 (:97-99)
+        const uint32_t n = kind == 0 ? L.tris.prim_count : (kind == 1 ? L.spheres.prim_count : L.quads.prim_count);
+        const float pad = (kind == 1 ? sc.light_pad_sphere : sc.light_pad_flat) * o_max;
+        // (corner - origin) * inv as one fused multiply-add each; the rounding this changes is far inside the padding
+        const f3 lo_c = mk3(-((o.x + pad) * inv.x), -((o.y + pad) * inv.y), -((o.z + pad) * inv.z));
+        const f3 hi_c = mk3(-((o.x - pad) * inv.x), -((o.y - pad) * inv.y), -((o.z - pad) * inv.z));
+        for (uint32_t base = first; base < first + n; base += 32u) {
+            const uint32_t count = first + n - base < 32u ? first + n - base : 32u;
+            uint32_t maybe = 0;
+#pragma unroll 8
+            for (uint32_t j = 0; j < count; j++) {
+                const light_box_t b = boxes[base + j];
+                const float ax = __builtin_fmaf(b[0], inv.x, lo_c.x), bx = __builtin_fmaf(b[4], inv.x, hi_c.x);
+                const float ay = __builtin_fmaf(b[1], inv.y, lo_c.y), by = __builtin_fmaf(b[5], inv.y, hi_c.y);
+                const float az = __builtin_fmaf(b[2], inv.z, lo_c.z), bz = __builtin_fmaf(b[6], inv.z, hi_c.z);
+                const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+                const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                if (!(t_in > t_out)) maybe |= 1u << j;
+            }
+            if (!ordinary) maybe = count == 32u ? 0xFFFFFFFFu : (1u << count) - 1u;
+            while (maybe != 0) {
+                const uint32_t j = (uint32_t)__ffs((int)maybe) - 1u;
+                maybe &= maybe - 1u;
+                pdf += light_term<TRIS_BY_SOLID_ANGLE>(sc, base + j, o, d);
+            }
+        }
+        first += n;
+    }
     return pdf / (float)sc.n_light_total;
 }
 

@@ -680,7 +680,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
             std::memcpy(d.rmax, wb.rmax, 12);
             d.tree = 1;
             depth_of[k][type] = wb.depth;
-        } else if (type == 0 && ctx->device_bvh_min && b.prim_count >= ctx->device_bvh_min) {
+        } else if (type == 0 && k != 1 && ctx->device_bvh_min && b.prim_count >= ctx->device_bvh_min) {  // lights are never traversed
             d.wide_first = (uint32_t)(wide.size() / 4);
             wide.resize(wide.size() + 4 * (size_t)(b.prim_count - 1), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             d.tree = 2;  // root and box follow from the build below
@@ -788,6 +788,65 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         d.moving_delta = pd;
         d.n_moving = s->n_moving;
         d.n_static_spheres = s->n_spheres - s->n_moving;
+    }
+    {
+        // A box around every light, for light_pdf to skip the lights a ray cannot hit.  The exact tests
+        // (Triangle::hit, Sphere::hit, Quad::hit in f32) accept rays whose exact line passes a little
+        // outside the primitive.  For triangles and quads that is a few ulp of (|origin| + |light|).  A
+        // sphere's discriminant h^2 - |d|^2 (|oc|^2 - r^2) carries an absolute error of up to about
+        // 13 * 2^-24 |d|^2 |oc|^2, so a ray may miss a small, distant sphere by sqrt(8e-7) |oc| and still
+        // count as a hit; with |oc| <= sqrt(3) (|origin| + |light|) in largest-coordinate terms that is
+        // 1.6e-3 (|origin| + |light|).  The boxes are widened by more than that.
+        const float rel_flat = 2.0e-5f, rel_sphere = 4.0e-3f;
+        const DevSet &L = sets[1];
+        std::vector<float4> boxes;
+        auto add_box = [&](const float *lo, const float *hi, float rel, bool finite) {
+            if (!finite) {  // never skipped
+                boxes.push_back(make_float4(-INFINITY, -INFINITY, -INFINITY, 0.0f));
+                boxes.push_back(make_float4(INFINITY, INFINITY, INFINITY, 0.0f));
+                return;
+            }
+            float m = 0.0f;
+            for (int k = 0; k < 3; k++) m = std::max(m, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+            const float pad = rel * m + 1.0e-30f;
+            boxes.push_back(make_float4(lo[0] - pad, lo[1] - pad, lo[2] - pad, 0.0f));
+            boxes.push_back(make_float4(hi[0] + pad, hi[1] + pad, hi[2] + pad, 0.0f));
+        };
+        auto all_finite = [](const float *p, int n) {
+            bool ok = true;
+            for (int k = 0; k < n; k++) ok = ok && std::isfinite(p[k]);
+            return ok;
+        };
+        for (uint32_t i = 0; i < L.tris.prim_count; i++) {
+            const float *t = s->tri_data + 24 * (size_t)(L.tris.prim_first + i);
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; k++) {
+                lo[k] = std::min(t[3 * k], std::min(t[3 * k + 1], t[3 * k + 2]));
+                hi[k] = std::max(t[3 * k], std::max(t[3 * k + 1], t[3 * k + 2]));
+            }
+            add_box(lo, hi, rel_flat, all_finite(t, 9));
+        }
+        for (uint32_t i = 0; i < L.spheres.prim_count; i++) {
+            const float *c = s->spheres + 4 * (size_t)(L.spheres.prim_first + i);
+            const float r = std::fabs(c[3]);
+            const float lo[3] = {c[0] - r, c[1] - r, c[2] - r}, hi[3] = {c[0] + r, c[1] + r, c[2] + r};
+            add_box(lo, hi, rel_sphere, all_finite(c, 4));
+        }
+        for (uint32_t i = 0; i < L.quads.prim_count; i++) {
+            const float *q = s->quads + 17 * (size_t)(L.quads.prim_first + i);  // origin, u, v, ...
+            float lo[3], hi[3];
+            for (int k = 0; k < 3; k++) {
+                const float a = q[k], b = q[k] + q[3 + k], c = q[k] + q[6 + k], e = (q[k] + q[3 + k]) + q[6 + k];
+                lo[k] = std::min(std::min(a, b), std::min(c, e));
+                hi[k] = std::max(std::max(a, b), std::max(c, e));
+            }
+            add_box(lo, hi, rel_flat, all_finite(q, 9));
+        }
+        float4 *pb;
+        if ((rc = dev_upload(ctx, ctx->scene_allocs, &pb, boxes.data(), boxes.size()))) return rc;
+        d.light_boxes = pb;
+        d.light_pad_flat = rel_flat;
+        d.light_pad_sphere = rel_sphere;
     }
     d.world = sets[0];
     d.lights = sets[1];
@@ -1428,6 +1487,35 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
     return sync_all(ctx);
+}
+
+int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_solid_angle, float *out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "upload a scene before asking for light pdfs");
+    if (n == 0) return PT_OK;
+    if (!rays || !out) return fail(ctx, PT_ERR_INVALID, "NULL ray or output array");
+    if (n > (1ull << 30)) return fail(ctx, PT_ERR_INVALID, "too many rays in one call");
+    if (ctx->scene.n_light_total == 0) return fail(ctx, PT_ERR_STATE, "the scene has no lights");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_rays = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_rays, n * 8 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(float));
+    if (e != hipSuccess) {
+        if (d_rays) (void)hipFree(d_rays);
+        return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    hipStream_t st = ctx->stream;
+    e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_light_pdf, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, ctx->scene, d_rays, (uint32_t)n, tris_by_solid_angle, d_out);
+        e = hipMemcpyAsync(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(d_rays);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_light_pdf: %s", hipGetErrorString(e));
+    return PT_OK;
 }
 
 int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples) {
