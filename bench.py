@@ -69,6 +69,7 @@ def main():
                     help="nee: next-event estimation with shadow rays (not in the reference); no counted pass, so no roofline figure")
     ap.add_argument("--bsdf-probability", type=float, default=1.0,
                     help="BSDF_SAMPLE_PROBABILITY of the reference's mixture sampler (src/camera.rs:317); below 1 some rays are aimed at lights")
+    ap.add_argument("--lights", type=int, default=64, help="interior: number of emissive quads")
     ap.add_argument("--extensions", action="store_true", help="next_week_like with its noise texture, media and moving sphere")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -96,7 +97,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     builders = {"knob": lambda: scenes.knob(width=args.width), "cornell": lambda: scenes.cornell(width=args.width),
-                "dragon_box": lambda: scenes.dragon_box(width=args.width), "interior": lambda: scenes.interior(width=args.width),
+                "dragon_box": lambda: scenes.dragon_box(width=args.width), "interior": lambda: scenes.interior(width=args.width, n_lights=args.lights),
                 "next_week_like": lambda: scenes.next_week_like(width=args.width, extensions=args.extensions)}
     src = builders[args.scene]()
     host = HostScene(src)

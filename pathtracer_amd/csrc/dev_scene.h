@@ -65,6 +65,8 @@ struct DevScene {
     const uint32_t *tri_order;  // [n_tris] position at upload of the triangle now at each position
     const float4 *light_boxes;  // [2 * (light triangles + spheres + quads)] lower, upper corner of a box around each
                                 // light in LightBuffer order, already widened by the light's own share of light_pad
+    const float4 *light_group_boxes;  // the same around every 32 consecutive lights of a kind: the groups of the
+                                      // triangles, then those of the spheres, then those of the quads
     DevSet world;   // sets[0]
     DevSet lights;  // sets[1]
     uint32_t n_materials;

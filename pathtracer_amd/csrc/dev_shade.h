@@ -593,7 +593,8 @@ __device__ inline f3 medium_direction(Rng &rng) {
 // sum over all of them.  Each light has a box in sc.light_boxes, wide enough that a ray which passes
 // outside it is rejected by the exact test as well; the first loop tests up to 32 boxes with the same
 // control flow in every lane and notes the survivors in a bit mask, the second runs the exact tests of
-// those, lowest index first.
+// those, lowest index first.  With many lights of a kind, groups of 32 consecutive ones have a box of their
+// own (sc.light_group_boxes) and a lane opens only the groups its ray reaches.
 //
 // Triangle::pdf of the reference is 1 / area, a density over the triangle rather than over
 // directions (spheres and quads report a solid-angle density).  TRIS_BY_SOLID_ANGLE converts it,
@@ -647,6 +648,10 @@ __device__ inline float light_term(const DevScene &sc, uint32_t i, f3 o, f3 d) {
     return term;
 }
 typedef float light_box_t __attribute__((ext_vector_type(8)));  // lower corner, unused, upper corner, unused
+#ifndef PT_LIGHTS_FLAT_MAX
+#define PT_LIGHTS_FLAT_MAX 256u
+#endif
+constexpr uint32_t LIGHTS_FLAT_MAX = PT_LIGHTS_FLAT_MAX;  // more lights of one kind than this: boxes of groups of 32 are tested first
 template <bool TRIS_BY_SOLID_ANGLE = false>
 __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
     const DevSet &L = sc.lights;
@@ -664,35 +669,70 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
     const float dd = norm_squared(d);
     const bool ordinary = dd > 1.0e-30f && dd < 1.0e30f && o_max < 1.0e10f;
     float pdf = 0.0f;
-    uint32_t first = 0;
+    uint32_t first = 0, first_group = 0;
 #pragma nounroll
     for (int kind = 0; kind < 3; kind++) {  // triangles, spheres, quads; instances: Hittable::pdf default, 0 (:97-99)
         const uint32_t n = kind == 0 ? L.tris.prim_count : (kind == 1 ? L.spheres.prim_count : L.quads.prim_count);
+        const uint32_t n_groups = (n + 31u) / 32u;
         const float pad = (kind == 1 ? sc.light_pad_sphere : sc.light_pad_flat) * o_max;
         // (corner - origin) * inv as one fused multiply-add each; the rounding this changes is far inside the padding
         const f3 lo_c = mk3(-((o.x + pad) * inv.x), -((o.y + pad) * inv.y), -((o.z + pad) * inv.z));
         const f3 hi_c = mk3(-((o.x - pad) * inv.x), -((o.y - pad) * inv.y), -((o.z - pad) * inv.z));
-        for (uint32_t base = first; base < first + n; base += 32u) {
-            const uint32_t count = first + n - base < 32u ? first + n - base : 32u;
-            uint32_t maybe = 0;
-#pragma unroll 8
-            for (uint32_t j = 0; j < count; j++) {
-                const light_box_t b = boxes[base + j];
-                const float ax = __builtin_fmaf(b[0], inv.x, lo_c.x), bx = __builtin_fmaf(b[4], inv.x, hi_c.x);
-                const float ay = __builtin_fmaf(b[1], inv.y, lo_c.y), by = __builtin_fmaf(b[5], inv.y, hi_c.y);
-                const float az = __builtin_fmaf(b[2], inv.z, lo_c.z), bz = __builtin_fmaf(b[6], inv.z, hi_c.z);
-                const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-                const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                if (!(t_in > t_out)) maybe |= 1u << j;
-            }
-            if (!ordinary) maybe = count == 32u ? 0xFFFFFFFFu : (1u << count) - 1u;
+        auto reaches = [&](const light_box_t b) {
+            const float ax = __builtin_fmaf(b[0], inv.x, lo_c.x), bx = __builtin_fmaf(b[4], inv.x, hi_c.x);
+            const float ay = __builtin_fmaf(b[1], inv.y, lo_c.y), by = __builtin_fmaf(b[5], inv.y, hi_c.y);
+            const float az = __builtin_fmaf(b[2], inv.z, lo_c.z), bz = __builtin_fmaf(b[6], inv.z, hi_c.z);
+            const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+            const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+            return !(t_in > t_out);
+        };
+        auto all_of = [](uint32_t count) { return count == 32u ? 0xFFFFFFFFu : (1u << count) - 1u; };
+        auto exact = [&](uint32_t base, uint32_t maybe) {  // the candidates of one group, lowest index first
             while (maybe != 0) {
                 const uint32_t j = (uint32_t)__ffs((int)maybe) - 1u;
                 maybe &= maybe - 1u;
                 pdf += light_term<TRIS_BY_SOLID_ANGLE>(sc, base + j, o, d);
             }
+        };
+        if (n <= LIGHTS_FLAT_MAX) {
+            // few lights: every lane looks at every box, the same one at the same time
+            for (uint32_t g = 0; g < n_groups; g++) {
+                const uint32_t base = first + 32u * g;
+                const uint32_t count = first + n - base < 32u ? first + n - base : 32u;
+                uint32_t maybe = 0;
+#pragma unroll 8
+                for (uint32_t j = 0; j < count; j++)
+                    if (reaches(boxes[base + j])) maybe |= 1u << j;
+                if (!ordinary) maybe = all_of(count);
+                exact(base, maybe);
+            }
+        } else {
+            // many lights: the boxes of whole groups of 32 first, the same way; then each lane looks into the
+            // groups its own ray reaches, lowest first (the loads are no longer the same in every lane)
+            const __attribute__((address_space(4))) light_box_t *group_boxes = (const __attribute__((address_space(4))) light_box_t *)sc.light_group_boxes;
+            for (uint32_t g0 = 0; g0 < n_groups; g0 += 32u) {
+                const uint32_t n_here = n_groups - g0 < 32u ? n_groups - g0 : 32u;
+                uint32_t groups = 0;
+#pragma unroll 8
+                for (uint32_t j = 0; j < n_here; j++)
+                    if (reaches(group_boxes[first_group + g0 + j])) groups |= 1u << j;
+                if (!ordinary) groups = all_of(n_here);
+                while (groups != 0) {
+                    const uint32_t g = g0 + (uint32_t)__ffs((int)groups) - 1u;
+                    groups &= groups - 1u;
+                    const uint32_t base = first + 32u * g;
+                    const uint32_t count = first + n - base < 32u ? first + n - base : 32u;
+                    uint32_t maybe = 0;
+#pragma nounroll
+                    for (uint32_t j = 0; j < count; j++)
+                        if (reaches(((const light_box_t *)sc.light_boxes)[base + j])) maybe |= 1u << j;
+                    if (!ordinary) maybe = all_of(count);
+                    exact(base, maybe);
+                }
+            }
         }
         first += n;
+        first_group += n_groups;
     }
     return pdf / (float)sc.n_light_total;
 }

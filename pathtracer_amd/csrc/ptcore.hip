@@ -842,9 +842,27 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
             }
             add_box(lo, hi, rel_flat, all_finite(q, 9));
         }
+        // and around every 32 consecutive lights of a kind
+        std::vector<float4> groups;
+        size_t at = 0;
+        for (uint32_t n : {L.tris.prim_count, L.spheres.prim_count, L.quads.prim_count}) {
+            for (uint32_t g = 0; g < n; g += 32u) {
+                float4 lo = boxes[2 * (at + g)], hi = boxes[2 * (at + g) + 1];
+                for (uint32_t j = g + 1; j < std::min(n, g + 32u); j++) {
+                    const float4 a = boxes[2 * (at + j)], b = boxes[2 * (at + j) + 1];
+                    lo = make_float4(std::min(lo.x, a.x), std::min(lo.y, a.y), std::min(lo.z, a.z), 0.0f);
+                    hi = make_float4(std::max(hi.x, b.x), std::max(hi.y, b.y), std::max(hi.z, b.z), 0.0f);
+                }
+                groups.push_back(lo);
+                groups.push_back(hi);
+            }
+            at += n;
+        }
         float4 *pb;
         if ((rc = dev_upload(ctx, ctx->scene_allocs, &pb, boxes.data(), boxes.size()))) return rc;
         d.light_boxes = pb;
+        if ((rc = dev_upload(ctx, ctx->scene_allocs, &pb, groups.data(), groups.size()))) return rc;
+        d.light_group_boxes = pb;
         d.light_pad_flat = rel_flat;
         d.light_pad_sphere = rel_sphere;
     }

@@ -81,11 +81,13 @@ def _same_bits(a, b):
 
 
 @pytest.mark.parametrize("solid_angle_tris", [False, True])
-def test_every_ray_gets_the_reference_sum_over_all_lights(solid_angle_tris):
+@pytest.mark.parametrize("sizes", [(40, 30, 60), (300, 280, 400)], ids=["130_lights", "980_lights"])
+def test_every_ray_gets_the_reference_sum_over_all_lights(sizes, solid_angle_tris):
+    """With more than 256 lights of a kind the device tests boxes around groups of 32 lights before the lights' own."""
     from oracle.pyoracle import OracleScene
     from pathtracer_amd.core import HostScene, Renderer
-    src, targets = _zoo()
-    rays = _rays(targets, seed=11)
+    src, targets = _zoo(5, *sizes)
+    rays = _rays(targets, seed=11, n_origins=24 if sizes[0] == 40 else 4)
     ref = OracleScene(src).light_pdfs(rays, solid_angle_tris)
     got = Renderer(HostScene(src)).light_pdf(rays, solid_angle_tris)
     same = _same_bits(got, ref)
