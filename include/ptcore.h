@@ -174,7 +174,7 @@ enum {
     PT_OPT_BLOCKS_PER_CU = 8,           /* resident workgroups per CU of the traversal kernels; 1..5, default 5 */
     PT_OPT_ROLLING = 10,                /* paths started per launch of the rolling schedule, in which every launch carries
                                            bounce 0 of a new batch together with the later bounces of the batches before it;
-                                           0 = one batch at a time per pipe; default 8388608 */
+                                           0 = one batch at a time per pipe; default 12000000 */
     PT_OPT_DEVICE_BVH = 11,             /* a triangle buffer that is uploaded without nodes and has at least this many
                                            triangles gets its BVH built on the device during pt_upload_scene (a different
                                            tree from the host builder's: same closest distances, the winner among exact

@@ -112,7 +112,7 @@ struct pt_context {
     Roll rolls[MAX_PIPES];
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
     int64_t roll_k = -1;             // strata per tick decided for the current scene, camera and options (-1: not yet)
-    uint64_t roll_paths = 1u << 23;  // paths started per tick; 0 = one batch at a time per pipe
+    uint64_t roll_paths = 12000000;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;       // batch-at-a-time schedule
     int n_roll_pipes = 2;  // rolling schedule: its launches are all large, two pipes cover each other's ramps
     uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
