@@ -179,6 +179,8 @@ static void free_pool(pt_context *ctx, std::vector<std::pair<void *, size_t>> &p
     pool.clear();
 }
 
+// workgroups of a traversal kernel that fit a CU's 160 KB of LDS with their lane stacks
+constexpr int MAX_WALK_BLOCKS = 163840 / (LDS_LEVELS * BLOCK * 8 + 1024);
 static int grid_for(const pt_context *ctx, uint64_t n) {
     uint64_t blocks = (n + BLOCK - 1) / BLOCK;
     uint64_t cap = (uint64_t)ctx->n_cu * 8;
@@ -397,7 +399,8 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             ctx->refill_below = (int)value;
             return PT_OK;
         case PT_OPT_BLOCKS_PER_CU:
-            if (!(value >= 1.0 && value <= 5.0)) return fail(ctx, PT_ERR_INVALID, "workgroups per CU must be in [1,5] (LDS holds five traversal stacks)");
+            if (!(value >= 1.0 && value <= (double)MAX_WALK_BLOCKS))
+                return fail(ctx, PT_ERR_INVALID, "workgroups per CU must be in [1,%d] (LDS holds that many traversal stacks)", MAX_WALK_BLOCKS);
             sync_pipes(ctx);
             ctx->blocks_per_cu = (int)value;
             for (auto &pp : ctx->pipes) {  // the stack overflow area is sized by the launch width
