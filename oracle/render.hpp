@@ -319,7 +319,7 @@ struct Scene {
             if (!material) return L;
             if (material->is_emissive()) {
                 float w = 1.0f;
-                if (prev_pdf > 0.0f && prev_pdf < INFINITY) w = prev_pdf / (prev_pdf + lights.pdf_nee(ray));
+                if (lights.objects.len() != 0 && prev_pdf > 0.0f && prev_pdf < INFINITY) w = prev_pdf / (prev_pdf + lights.pdf_nee(ray));
                 return L + cmul(beta, shading.emitted(*material, rec)) * w;
             }
             ONB surface = ONB::make(rec.normal);

@@ -370,7 +370,7 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
         if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v, s.p);
         if constexpr (NEE) {
             float w = 1.0f;
-            if (b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true>(sc, ro, rd));
+            if (sc.n_light_total != 0u && b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true>(sc, ro, rd));
             const float4 c = ps.contrib[slot];
             const f3 add = cmul(beta, e) * w;
             ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);

@@ -1326,6 +1326,9 @@ static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
     if (!ctx->have_scene || !ctx->have_camera) return fail(ctx, PT_ERR_STATE, "upload a scene and set a camera before rendering");
     const uint64_t total = (uint64_t)ctx->cam.sqrt_spp * ctx->cam.sqrt_spp;
     if (b > e || e > total) return fail(ctx, PT_ERR_INVALID, "stratum range [%u,%u) outside [0,%llu)", b, e, (unsigned long long)total);
+    // LightBuffer::sample draws gen_range(0..lights.len()) (src/objects.rs:236-237): rand panics on an empty range
+    if (!ctx->nee && ctx->bsdf_prob < 1.0f && ctx->scene.n_light_total == 0)
+        return fail(ctx, PT_ERR_INVALID, "BSDF_SAMPLE_PROBABILITY below 1 needs a light to sample, and the scene has none");
     if (ctx->nee && (ctx->scene.n_media != 0 || ctx->scene.n_moving != 0))
         return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation does not handle participating media or moving spheres");
     if (ctx->scene.n_moving != 0 && (ctx->counters || !ctx->use_wide()))

@@ -125,3 +125,12 @@ def test_a_scene_without_lights_is_refused():
     r = Renderer(HostScene(s))
     with pytest.raises(PtError):
         r.light_pdf(np.zeros((1, 8), np.float32))
+    # and so is sampling lights that do not exist: the reference panics in gen_range(0..0) (src/objects.rs:236-237)
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_INTEGRATOR
+    r.render(0, 1, seed=1)
+    r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, 0.5)
+    with pytest.raises(PtError):
+        r.render(0, 1, seed=1)
+    r.set_option(PT_OPT_INTEGRATOR, 1)     # next-event estimation simply finds no light to aim at
+    r.render(0, 1, seed=1)
+    assert np.isfinite(r.read_accum()[0]).all()
