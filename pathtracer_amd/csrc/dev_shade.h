@@ -744,10 +744,12 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
 // NaN when the origin lies inside the sphere and infinite when the sphere is so small or far that the
 // root rounds to 1; it counts only if the ray hits that sphere.  So this returns 0, or NaN in those
 // cases, from the sphere lights' own terms: the intersection test per light and vertex of the full sum
-// is not needed for a product with zero.
+// is not needed for a product with zero.  Without any light the reference's average is 0 / 0: every
+// vertex with a non-specular material then ends its path with nothing (src/camera.rs:355-357).
 __device__ inline float light_pdf_times_zero(const DevScene &sc, f3 o, f3 d) {
     const DevSet &L = sc.lights;
-    float r = 0.0f;
+    // an empty LightBuffer: the sum, 0, divided by the number of lights, 0 (src/objects.rs:260, :277)
+    float r = sc.n_light_total == 0u ? NAN : 0.0f;
     TravCounters tc{0, 0, 0, 0};
     for (uint32_t i = 0; i < L.spheres.prim_count; i++) {
         const uint32_t g = L.spheres.prim_first + i;

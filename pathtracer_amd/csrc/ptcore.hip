@@ -112,6 +112,7 @@ struct pt_context {
     Roll rolls[MAX_PIPES];
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
     int64_t roll_k = -1;             // strata per tick decided for the current scene, camera and options (-1: not yet)
+    uint64_t untraced_paths = 0;  // camera paths of renders with max_depth 0, which start and end on the host
     uint64_t roll_paths = 12000000;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;       // batch-at-a-time schedule
     int n_roll_pipes = 2;  // rolling schedule: its launches are all large, two pipes cover each other's ramps
@@ -1348,6 +1349,12 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     // the share of its thin late bounces; consecutive calls keep the other pipes busy.
     const uint32_t total = stratum_end - stratum_begin;
     if (total == 0) return PT_OK;
+    if (ctx->cam.max_depth == 0) {
+        // ray_color returns zeros before it traces anything (src/camera.rs:271-273): the passes count, and add nothing
+        ctx->n_samples += total;
+        ctx->untraced_paths += (uint64_t)total * npix;
+        return PT_OK;
+    }
     if (const uint32_t k_tick = roll_strata(ctx)) {
         const uint32_t depth = ctx->cam.max_depth, cap_slots = npix * k_tick;
         bool fits = true;
@@ -1429,6 +1436,12 @@ int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_
     const bool prof = ctx->profile;
     ctx->profile = false;
     std::vector<float4> host;
+    if (ctx->cam.max_depth == 0) {  // as in pt_render: nothing is traced
+        std::memset(out, 0, (size_t)(stratum_end - stratum_begin) * npix * 3 * sizeof(float));
+        ctx->untraced_paths += (uint64_t)(stratum_end - stratum_begin) * npix;
+        ctx->profile = prof;
+        return PT_OK;
+    }
     for (uint32_t s = stratum_begin; s < stratum_end;) {
         const uint32_t k = std::min(per_batch, stratum_end - s);
         if ((rc = run_batch(ctx, pp, s, k, seed))) break;
@@ -1613,7 +1626,7 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
     HIP_TRY(ctx, hipMemcpy(&ds, ctx->stats, sizeof ds, hipMemcpyDeviceToHost));
     std::memset(out, 0, sizeof *out);
     out->rays = ds.rays_total;
-    out->paths = ds.paths_total;
+    out->paths = ds.paths_total + ctx->untraced_paths;
     out->extend_launches = ds.extend_nonempty;
     out->extend_ms = ctx->extend_ms;
     out->extend_busy_ms = ctx->extend_busy_ms;
@@ -1645,6 +1658,7 @@ int pt_stats_reset(pt_context *ctx) {
     if (int rc = restart_epoch(ctx)) return rc;
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
     ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = ctx->host_wait_ms = 0.0;
+    ctx->untraced_paths = 0;
     ctx->bounce_extend_ms.clear();
     ctx->bounce_shade_ms.clear();
     ctx->profiled_batches = 0;

@@ -1,0 +1,114 @@
+"""Smallest and emptiest inputs through the C ABI: scenes without primitives, of one primitive type only, one-pixel
+images, one stratum, depth 0 and 1, empty stratum ranges, empty ray lists.  Each against the oracle where there
+is something to compare (the reference's tests hold no such cases; these are the edges of its own loops:
+src/camera.rs:176-198 over strata and pixels, src/objects.rs:191-197 over the four buffers)."""
+import numpy as np
+import pytest
+
+from pathtracer_amd.scene_src import CameraSrc, SceneSource
+from tests.util import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _camera(width=8, spp=4, depth=4, background=(0.25, 0.5, 0.75)):
+    return CameraSrc(1.0, width, 40.0, (0.0, 1.0, -6.0), (0.0, 0.0, 0.0), 1.0, 0.0, spp, depth, background)
+
+
+def _pair(src):
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import HostScene, Renderer
+    return OracleScene(src), Renderer(HostScene(src))
+
+
+def _same_image(src, strata, seed=3):
+    o, r = _pair(src)
+    ref = np.nan_to_num(o.render(0, strata, seed=seed, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, strata, seed=seed), nan=0.0, posinf=0.0, neginf=0.0)
+    assert got.shape == ref.shape
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() >= 0.99, close.mean()
+    return o, r
+
+
+def test_a_scene_with_nothing_in_it_shows_the_background():
+    s = SceneSource()
+    s.name = "void"
+    s.camera = _camera()
+    o, r = _pair(s)
+    r.render(0, 4, seed=1)
+    acc, n = r.read_accum()
+    assert n == 4 and np.allclose(acc, 4 * np.array([0.25, 0.5, 0.75], np.float32))
+    assert bits_equal(acc, o.render(0, 4, seed=1)["accum"])
+    rays = r.generate_rays(0, seed=1)
+    assert (r.trace(rays)["prim_type"] == -1).all()
+    assert r.stats()["rays"] == 4 * r.npix
+
+
+@pytest.mark.parametrize("kind", ["tris", "spheres", "quads", "instances"])
+@pytest.mark.parametrize("bvh", [False, True])
+@pytest.mark.parametrize("lit", [False, True])
+def test_one_primitive_type_alone(kind, bvh, lit):
+    """Without a light the reference's LightBuffer::pdf is 0 / 0 (src/objects.rs:260, :277) and every diffuse vertex ends
+    its path in black (src/camera.rs:355-357); with one, of the same primitive type, paths go on."""
+    from pathtracer_amd.scene_src import InstanceSrc, new_box
+    s = SceneSource()
+    s.name = "only_" + kind
+    m = s.lambertian((0.6, 0.5, 0.4))
+    if lit:
+        e = s.diffuse_light_texture(s.solid((4.0, 4.0, 4.0)))
+        for target in (s.objects, s.lights):
+            if kind == "tris":
+                target.add_triangles(np.array([[[-3, 4, -1], [3, 4, -1], [0, 4, 3]]], np.float32), None, None, e)
+            elif kind == "spheres":
+                target.add_sphere((0.0, 5.0, 0.0), 1.5, e)
+            elif kind == "quads":
+                target.add_quad((-2, 4, -1), (4, 0, 0), (0, 0, 3), e)
+        if kind == "instances":
+            s.objects.add_instance(InstanceSrc(new_box((-1, 4, -1), (1, 4.5, 1), e)))
+            s.lights.add_quad((-1, 4, -1), (2, 0, 0), (0, 0, 2), e)
+    if kind == "tris":
+        s.objects.add_triangles(np.array([[[-2, -1, 0], [2, -1, 0], [0, 2, 0]], [[-2, -1, 1], [2, -1, 1], [0, 2, 1]]], np.float32), None, None, m)
+    elif kind == "spheres":
+        s.objects.add_sphere((0.0, 0.0, 0.0), 1.0, m)
+        s.objects.add_sphere((1.5, 0.5, 1.0), 0.7, m)
+    elif kind == "quads":
+        s.objects.add_quad((-2, -1, 0), (4, 0, 0), (0, 3, 0), m)
+        s.objects.add_quad((-2, -1, 0), (4, 0, 0), (0, 0, 4), m)
+    else:
+        s.objects.add_instance(InstanceSrc(new_box((-1, -1, -1), (1, 1, 1), m)).rotate_y(0.5))
+        s.objects.add_instance(InstanceSrc(new_box((-1, -1, -1), (1, 1, 1), m)).translate((2.5, 0.0, 1.0)))
+    s.objects.build_bvh = bvh
+    s.camera = _camera(width=12, spp=4)
+    o, r = _same_image(s, 4)
+    rays = r.generate_rays(1, seed=2)
+    ho, hd = o.trace(rays), r.trace(rays)
+    assert np.array_equal(hd["prim_type"], ho[0][:, 0]) and np.array_equal(hd["prim_id"], ho[0][:, 1])
+    assert bits_equal(hd["t"][hd["prim_type"] >= 0], ho[1][:, 0][hd["prim_type"] >= 0])
+
+
+@pytest.mark.parametrize("width,spp,depth", [(1, 1, 1), (1, 4, 3), (3, 1, 1), (5, 9, 0), (2, 4, 300)])
+def test_smallest_images_sample_counts_and_depths(width, spp, depth):
+    """Depth 0 returns black without tracing (src/camera.rs:271-273); depth 300 is beyond what the shared launches take."""
+    from pathtracer_amd import scenes
+    src = scenes.cornell(width, spp, max_depth=depth)
+    strata = int(np.floor(np.sqrt(spp))) ** 2
+    o, r = _same_image(src, strata)
+    r.render(0, strata, seed=3)
+    acc, n = r.read_accum()
+    assert n == strata and acc.shape == (r.npix, 3)
+    if depth == 0:
+        assert not acc.any() and r.stats()["rays"] == 0
+
+
+def test_empty_ranges_and_lists_do_nothing():
+    from pathtracer_amd import scenes
+    _, r = _pair(scenes.cornell(8, 4))
+    r.render(2, 2, seed=1)
+    acc, n = r.read_accum()
+    assert n == 0 and not acc.any()
+    assert r.trace(np.zeros((0, 8), np.float32)).shape == (0,)
+    assert r.light_pdf(np.zeros((0, 8), np.float32)).shape == (0,)
+    assert r.render_samples(1, 1, seed=1).shape == (0, r.npix, 3)
+    r.render(0, 4, seed=1)
+    assert r.read_accum()[1] == 4
