@@ -319,7 +319,10 @@ struct Scene {
             if (!material) return L;
             if (material->is_emissive()) {
                 float w = 1.0f;
-                if (lights.objects.len() != 0 && prev_pdf > 0.0f && prev_pdf < INFINITY) w = prev_pdf / (prev_pdf + lights.pdf_nee(ray));
+                // the density with which light sampling draws this direction, whatever lies along it: a fresh ray, since
+                // `ray` now ends at the emitter and a light behind it would no longer count
+                if (lights.objects.len() != 0 && prev_pdf > 0.0f && prev_pdf < INFINITY)
+                    w = prev_pdf / (prev_pdf + lights.pdf_nee(Ray::make(ray.origin, ray.direction)));
                 return L + cmul(beta, shading.emitted(*material, rec)) * w;
             }
             ONB surface = ONB::make(rec.normal);

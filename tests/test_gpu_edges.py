@@ -112,3 +112,69 @@ def test_empty_ranges_and_lists_do_nothing():
     assert r.render_samples(1, 1, seed=1).shape == (0, r.npix, 3)
     r.render(0, 4, seed=1)
     assert r.read_accum()[1] == 4
+
+
+def _odd_scene(which):
+    from pathtracer_amd.scene_src import InstanceSrc, new_box
+    s = SceneSource()
+    s.name = "odd_" + which
+    grey = s.lambertian((0.7, 0.7, 0.7))
+    e = s.diffuse_light_texture(s.solid((5.0, 4.0, 3.0)))
+    s.objects.add_quad((-4, -1, -4), (8, 0, 0), (0, 0, 8), grey)
+    if which == "no_material":
+        # Sphere::new(.., None): the path that reaches it returns nothing (src/camera.rs:286-287)
+        s.objects.add_sphere((0.0, 0.0, 0.0), 1.0, -1)
+        s.objects.add_quad((-2, 3, -2), (4, 0, 0), (0, 0, 4), e)
+        s.lights.add_quad((-2, 3, -2), (4, 0, 0), (0, 0, 4), e)
+    elif which == "light_seen_from_behind":
+        # Diffuse::emitted is zero on the back face (src/materials/light.rs:42-47): this quad faces up, away from the floor
+        s.objects.add_quad((-2, 3, -2), (0, 0, 4), (4, 0, 0), e)
+        s.lights.add_quad((-2, 3, -2), (0, 0, 4), (4, 0, 0), e)
+        s.objects.add_sphere((0.0, 0.0, 0.0), 1.0, s.metal((0.9, 0.9, 0.9), 0.0))
+    elif which == "mirrors_and_glass":
+        # specular vertices only between the camera and the light: no pdf, no roulette (src/camera.rs:298-313)
+        s.objects.add_sphere((-1.2, 0.0, 0.0), 1.0, s.metal((0.9, 0.8, 0.7), 0.3))
+        s.objects.add_sphere((1.2, 0.0, 0.0), 1.0, s.dielectric(1.5))
+        s.objects.add_sphere((1.2, 0.0, 0.0), -0.8, s.dielectric(1.5))   # hollow, as in the book's scenes
+        s.objects.add_quad((-3, 4, -3), (6, 0, 0), (0, 0, 6), e)
+        s.lights.add_quad((-3, 4, -3), (6, 0, 0), (0, 0, 6), e)
+    elif which == "instance_in_the_light_list":
+        # Hittable::pdf and ::sample defaults: pdf 0 and a zero vector (src/objects.rs:97-102)
+        box = InstanceSrc(new_box((-1, 3, -1), (1, 3.5, 1), e))
+        s.objects.add_instance(box)
+        s.lights.add_instance(InstanceSrc(new_box((-1, 3, -1), (1, 3.5, 1), e)))
+        s.lights.add_quad((-3, 4, -3), (6, 0, 0), (0, 0, 6), e)
+        s.objects.add_quad((-3, 4, -3), (6, 0, 0), (0, 0, 6), e)
+        s.objects.add_sphere((0.0, 0.0, 0.0), 1.0, grey)
+    s.camera = _camera(width=16, spp=16, depth=8, background=(0.02, 0.03, 0.05))
+    return s
+
+
+@pytest.mark.parametrize("which", ["no_material", "light_seen_from_behind", "mirrors_and_glass", "instance_in_the_light_list"])
+@pytest.mark.parametrize("prob", [1.0, 0.5])
+def test_corners_of_ray_color(which, prob):
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY
+    src = _odd_scene(which)
+    o, r = _pair(src)
+    o.set_bsdf_probability(prob)
+    r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, prob)
+    ref = np.nan_to_num(o.render(0, 16, seed=9, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 16, seed=9), nan=0.0, posinf=0.0, neginf=0.0)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() >= 0.99, (which, prob, close.mean())
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
+    r.stats_reset()
+    r.render(0, 16, seed=9)
+    assert abs(r.stats()["rays"] - o.render(0, 16, seed=9)["rays"]) <= 0.01 * r.stats()["rays"]
+
+
+@pytest.mark.parametrize("which", ["no_material", "light_seen_from_behind", "mirrors_and_glass", "instance_in_the_light_list"])
+def test_the_same_corners_under_next_event_estimation(which):
+    from pathtracer_amd.core import PT_OPT_INTEGRATOR
+    o, r = _pair(_odd_scene(which))
+    r.set_option(PT_OPT_INTEGRATOR, 1)
+    ref = np.nan_to_num(o.render(0, 16, seed=9, iterative=2, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 16, seed=9), nan=0.0, posinf=0.0, neginf=0.0)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() >= 0.99, (which, close.mean())
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
