@@ -538,6 +538,8 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
 template <int MT, bool ROLL, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
     constexpr bool NEE = MODE == 1, MEDIA = MODE == 2;
+    // a path ends at an emitter (src/camera.rs:288-290), unless a medium scatters it on its way there
+    constexpr bool CONTINUES = MT != PTS_MAT_DIFFUSE_LIGHT || MEDIA;
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
                 alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, bp, slot, slot, shadow);
             }
         }
-        if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
+        if constexpr (CONTINUES) {
             survivors += (uint32_t)__popcll(__ballot(alive));
             wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
             if constexpr (NEE) {
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
             }
         }
     }
-    if constexpr (MT != PTS_MAT_DIFFUSE_LIGHT) {
+    if constexpr (CONTINUES) {
         wave_push_close(out, ps.ray_queue[parity ^ 1u]);
         if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
         if (survivors && lane_id() == 0u) {

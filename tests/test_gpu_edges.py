@@ -219,3 +219,40 @@ def test_bent_cameras_textures_and_a_squashed_instance(which):
         assert bits_equal(ro, rd)
         ho, hd = o.trace(rd), r.trace(rd)
         assert np.array_equal(hd["prim_type"], ho[0][:, 0]) and np.array_equal(hd["prim_id"], ho[0][:, 1]) and np.array_equal(hd["inst_id"], ho[0][:, 2])
+
+
+def _haze_scene(which):
+    """Corners of the two scene features the reference does not have: media and moving spheres."""
+    s = SceneSource()
+    s.name = "haze_" + which
+    grey = s.lambertian((0.7, 0.7, 0.7))
+    e = s.diffuse_light_texture(s.solid((6.0, 6.0, 6.0)))
+    s.objects.add_quad((-6, -1, -6), (12, 0, 0), (0, 0, 12), grey)
+    s.objects.add_quad((-2, 5, -2), (4, 0, 0), (0, 0, 4), e)
+    s.lights.add_quad((-2, 5, -2), (4, 0, 0), (0, 0, 4), e)
+    s.objects.add_sphere((0.0, 0.0, 0.0), 1.0, s.dielectric(1.5))
+    if which == "camera_inside":
+        s.add_medium((0.0, 1.0, -6.0), 3.0, 0.4, s.solid((0.9, 0.9, 0.9)))        # the camera sits at its centre
+    elif which == "overlapping":
+        s.add_medium((-0.5, 0.5, 0.0), 2.0, 0.7, s.solid((0.9, 0.3, 0.3)))
+        s.add_medium((0.5, 0.5, 0.0), 2.0, 0.7, s.solid((0.3, 0.3, 0.9)))
+        s.add_medium((0.0, 0.0, 0.0), 1.0, 5.0, s.noise((0.8, 0.8, 0.8), 3.0, seed=4))   # inside the glass ball, noise for albedo
+    elif which == "around_the_light":
+        s.add_medium((0.0, 5.0, 0.0), 3.0, 0.5, s.solid((0.8, 0.8, 0.8)))
+        s.add_medium((0.0, 0.0, 0.0), 5000.0, 1e-4, s.solid((1.0, 1.0, 1.0)))           # the mist of the Next Week scene
+    elif which == "fast_spheres":
+        s.add_moving_sphere((-3.0, 0.0, 1.0), (3.0, 2.0, 1.0), 0.6, grey)                  # crosses the whole view
+        s.add_moving_sphere((0.0, 3.0, 0.0), (0.0, 3.0, 0.0), 0.5, s.metal((0.9, 0.9, 0.9), 0.0))   # does not move
+        s.add_moving_sphere((0.0, 0.0, 0.0), (0.0, 0.5, 0.0), 0.4, e)                      # an emitter, inside the glass ball
+    s.camera = _camera(width=20, spp=16, depth=10, background=(0.05, 0.07, 0.1))
+    return s
+
+
+@pytest.mark.parametrize("which", ["camera_inside", "overlapping", "around_the_light", "fast_spheres"])
+def test_corners_of_media_and_motion(which):
+    src = _haze_scene(which)
+    o, r = _same_image(src, 16, seed=4)
+    r.stats_reset()
+    r.render(0, 16, seed=4)
+    want = o.render(0, 16, seed=4, iterative=True)["rays"]
+    assert abs(r.stats()["rays"] - want) <= 0.02 * want
