@@ -274,6 +274,14 @@ class Renderer:
         self.width, self.height, self.sqrt_spp = scene.width, scene.height, scene.sqrt_spp
         self.npix = self.width * self.height
 
+    def load(self, scene: HostScene):
+        """Another scene and camera into the same context (pt_upload_scene replaces the earlier scene)."""
+        self._check(self.L.pt_upload_scene(self.ctx, C.byref(scene.desc)), "pt_upload_scene")
+        self._check(self.L.pt_set_camera(self.ctx, C.byref(scene.camera)), "pt_set_camera")
+        self.scene = scene
+        self.width, self.height, self.sqrt_spp = scene.width, scene.height, scene.sqrt_spp
+        self.npix = self.width * self.height
+
     def _check(self, rc: int, what: str):
         if rc:
             raise PtError(f"{what} failed ({rc}): " + self.L.pt_last_error(self.ctx).decode())

@@ -268,3 +268,29 @@ def test_corners_of_media_and_motion(which):
     r.render(0, 16, seed=4)
     want = o.render(0, 16, seed=4, iterative=True)["rays"]
     assert abs(r.stats()["rays"] - want) <= 0.02 * want
+
+
+def test_one_context_many_scenes_and_two_contexts_at_once():
+    """pt_upload_scene replaces the scene (other material types, other queues), pt_set_camera the image size; contexts
+    do not share anything.  Each result must have the bits a fresh context gives."""
+    from pathtracer_amd import scenes
+    from pathtracer_amd.core import HostScene, Renderer
+    srcs = [scenes.cornell(24, 16), scenes.small_mixed(40, 16), _haze_scene("overlapping"), scenes.cornell(8, 4), _odd_scene("mirrors_and_glass")]
+    fresh = []
+    for src in srcs:
+        r = Renderer(HostScene(src))
+        r.render(0, 4, seed=6)
+        fresh.append(r.read_accum()[0])
+    one = Renderer(HostScene(srcs[0]))
+    for k, src in enumerate(srcs):
+        if k:
+            one.render(0, 2, seed=1)          # work under way when the scene is replaced
+            one.load(HostScene(src))
+        one.render(0, 4, seed=6)
+        acc, n = one.read_accum()
+        assert n == 4 and bits_equal(acc, fresh[k]), k
+    a, b = Renderer(HostScene(srcs[1])), Renderer(HostScene(srcs[2]))
+    for lo in range(4):                       # interleaved, neither waits for the other
+        a.render(lo, lo + 1, seed=6)
+        b.render(lo, lo + 1, seed=6)
+    assert bits_equal(a.read_accum()[0], fresh[1]) and bits_equal(b.read_accum()[0], fresh[2])
