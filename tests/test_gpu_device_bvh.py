@@ -107,3 +107,38 @@ def test_small_buffers_and_duplicate_centres(n):
     assert np.array_equal(a["prim_type"], b["prim_type"])
     if n < 9:  # no exact ties by construction
         assert np.array_equal(_original_tri_ids(host, rh, a), _original_tri_ids(dev, rd, b))
+
+
+def test_triangle_buffers_inside_instances_and_in_the_light_list():
+    """Every triangle buffer above the threshold gets a device tree, the children of instances included; the light
+    list is never traversed, so its triangles keep their order (LightBuffer::sample picks them by index)."""
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY
+    src = scenes.small_mixed(48, 16)
+    rng = np.random.default_rng(3)
+    c = rng.uniform(-3, 3, (40, 1, 3)) + np.array([0.0, 7.0, 0.0])
+    lights = (c + rng.normal(scale=0.2, size=(40, 3, 3))).astype(np.float32)   # 40 small emissive triangles near the ceiling
+    emit = src.diffuse_light_texture(src.solid((4.0, 4.0, 4.0)))
+    src.objects.add_triangles(lights, None, None, emit)
+    src.lights.add_triangles(lights, None, None, emit)
+    host, rh, dev, rd = _pair(src, device_from=8)
+    n_sets = host.desc.n_sets
+    assert n_sets > 2
+    built = [k for k in range(n_sets) if host.set_desc(k).tris.node_count > 0]
+    assert any(k >= 2 for k in built)                                            # a child of an instance holds a triangle tree
+    for k in built:
+        assert dev.set_desc(k).tris.node_count == 0                              # left to the device
+    rays = np.concatenate([_rays(40000, 5, -6, 6, towards=(0.0, 2.0, 0.0)), _rays(10000, 6, -5, 5)])
+    a, b = rh.trace(rays), rd.trace(rays)
+    _, tuv = OracleScene(src).trace(rays)
+    assert np.array_equal(a["t"].view(np.uint32), tuv[:, 0].view(np.uint32))
+    assert np.array_equal(b["t"].view(np.uint32), a["t"].view(np.uint32))
+    assert np.array_equal(a["prim_type"], b["prim_type"]) and np.array_equal(a["inst_id"], b["inst_id"])
+    # light sampling sees the same lights in the same order: same pdf for every ray, same image up to ties
+    assert np.array_equal(rh.light_pdf(rays).view(np.uint32), rd.light_pdf(rays).view(np.uint32))
+    for r in (rh, rd):
+        r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, 0.5)
+        r.render(0, 16, seed=3)
+    x, y = rh.read_accum()[0], rd.read_accum()[0]
+    same = np.all(np.nan_to_num(x).view(np.uint32).reshape(-1, 3) == np.nan_to_num(y).view(np.uint32).reshape(-1, 3), axis=1)
+    assert same.mean() > 0.99, f"{(~same).sum()} of {same.size} pixels differ"
