@@ -134,3 +134,24 @@ def test_a_scene_without_lights_is_refused():
     r.set_option(PT_OPT_INTEGRATOR, 1)     # next-event estimation simply finds no light to aim at
     r.render(0, 1, seed=1)
     assert np.isfinite(r.read_accum()[0]).all()
+
+
+@pytest.mark.parametrize("integrator", ["mixture", "nee"])
+def test_rendering_with_more_lights_than_the_flat_scan_takes(integrator):
+    """300 emissive quads: inside the shade kernels LightBuffer::pdf goes through the boxes around groups of lights."""
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_INTEGRATOR, HostScene, Renderer
+    src = scenes.interior(40, 16, n_lights=300, columns=3)
+    o, r = OracleScene(src), Renderer(HostScene(src))
+    if integrator == "nee":
+        r.set_option(PT_OPT_INTEGRATOR, 1)
+        ref = o.render(0, 4, seed=8, iterative=2, per_sample=True)["per_sample"]
+    else:
+        r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, 0.5)
+        o.set_bsdf_probability(0.5)
+        ref = o.render(0, 4, seed=8, iterative=True, per_sample=True)["per_sample"]
+    ref = np.nan_to_num(ref, nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 4, seed=8), nan=0.0, posinf=0.0, neginf=0.0)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() > 0.99, close.mean()
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
