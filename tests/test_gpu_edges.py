@@ -294,3 +294,23 @@ def test_one_context_many_scenes_and_two_contexts_at_once():
         a.render(lo, lo + 1, seed=6)
         b.render(lo, lo + 1, seed=6)
     assert bits_equal(a.read_accum()[0], fresh[1]) and bits_equal(b.read_accum()[0], fresh[2])
+
+
+@pytest.mark.parametrize("make,name", [(_odd_scene, "no_material"), (_odd_scene, "mirrors_and_glass"), (_odd_scene, "instance_in_the_light_list"),
+                                       (_bent_scene, "wide_lens"), (_haze_scene, "camera_inside"), (_haze_scene, "overlapping"),
+                                       (_haze_scene, "around_the_light")])
+def test_the_reference_order_traversal_gives_the_same_samples(make, name):
+    """PT_OPT_TRAVERSAL = 1 walks the 32-byte nodes as src/bvh.rs:725-797 does, PT_OPT_COUNTERS counts on the way; the
+    closest hits are the same, so every sample must have the same bits as with the two-box nodes."""
+    from pathtracer_amd.core import PT_OPT_COUNTERS, PT_OPT_TRAVERSAL, HostScene, Renderer
+    src = make(name)
+    want = Renderer(HostScene(src)).render_samples(0, 8, seed=12)
+    for option in (PT_OPT_TRAVERSAL, PT_OPT_COUNTERS):
+        r = Renderer(HostScene(src))
+        r.set_option(option, 1)
+        got = r.render_samples(0, 8, seed=12)
+        assert bits_equal(np.nan_to_num(got), np.nan_to_num(want)) and np.array_equal(np.isnan(got), np.isnan(want)), option
+        r.render(0, 8, seed=12)
+        if option == PT_OPT_COUNTERS:
+            st = r.stats()
+            assert st["node_tests"] + st["quad_tests"] + st["sphere_tests"] + st["tri_tests"] > 0
