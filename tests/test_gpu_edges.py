@@ -314,3 +314,17 @@ def test_the_reference_order_traversal_gives_the_same_samples(make, name):
         if option == PT_OPT_COUNTERS:
             st = r.stats()
             assert st["node_tests"] + st["quad_tests"] + st["sphere_tests"] + st["tri_tests"] > 0
+
+
+@pytest.mark.parametrize("which", ["overlapping", "fast_spheres"])
+def test_media_and_motion_with_rays_aimed_at_the_light(which):
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY
+    src = _haze_scene(which)
+    o, r = _pair(src)
+    o.set_bsdf_probability(0.6)
+    r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, 0.6)
+    ref = np.nan_to_num(o.render(0, 16, seed=2, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 16, seed=2), nan=0.0, posinf=0.0, neginf=0.0)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() >= 0.99, (which, close.mean())
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
