@@ -228,6 +228,17 @@ int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *ra
 /* PrimitiveBuffer::hit for n caller-supplied rays: rays[n][8] as above, out[n] (host memory). */
 int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out);
 
+/* No counterpart in the reference.  pt_trace_first_hit for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels,
+ * with everything they need beyond the rays and the hits (path state, the ray queue, the spilled part of
+ * the traversal stacks) in a fixed array that the library holds on every GPU it runs on (about 45 MB per
+ * GPU, until the process ends).  The call allocates and frees nothing.  rays_device[n][8] and
+ * out_device[n] are DEVICE memory of ctx's GPU; the call returns when out_device is complete.  At most
+ * PT_STATIC_TRACE_MAX_RAYS rays per call (PT_ERR_INVALID beyond that).  All contexts of one GPU share the
+ * array: two such calls that overlap in time on one GPU race; serialise them. */
+#define PT_STATIC_TRACE_MAX_RAYS 262144u
+int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_t n, pt_hit *out_device);
+
 /* LightBuffer::pdf (src/objects.rs:259-278) for n caller-supplied rays, of which only origin and
  * direction count: the sum of every light's pdf for the ray divided by the number of lights, out[n]
  * (host memory).  tris_by_solid_angle = 0 is the reference's Triangle::pdf, 1 / area

@@ -88,7 +88,7 @@ HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id"
 
 # every symbol include/ptcore.h and include/pthost.h declare
 CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
-                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_light_pdf", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
+                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_trace_first_hit_static", "pt_light_pdf", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
                 "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
 HOST_SYMBOLS = ["pth_scene_build", "pth_scene_build_opts", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
                 "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles"]
@@ -113,6 +113,7 @@ def core_lib() -> C.CDLL:
         L.pt_render_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
         L.pt_generate_rays.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
         L.pt_trace_first_hit.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pt_trace_first_hit_static.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_light_pdf.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
         L.pt_read_accum.argtypes = [vp, vp, vp]
         L.pt_read_rgb8.argtypes = [vp, vp]
@@ -325,6 +326,10 @@ class Renderer:
         out = np.zeros(rays.shape[0], HIT_DTYPE)
         self._check(self.L.pt_trace_first_hit(self.ctx, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p)), "pt_trace_first_hit")
         return out
+
+    def trace_static(self, rays_device: int, n: int, out_device: int):
+        """pt_trace_first_hit_static: rays and hits are device addresses; nothing is allocated."""
+        self._check(self.L.pt_trace_first_hit_static(self.ctx, C.c_void_p(rays_device), n, C.c_void_p(out_device)), "pt_trace_first_hit_static")
 
     def light_pdf(self, rays: np.ndarray, tris_by_solid_angle: bool = False) -> np.ndarray:
         """LightBuffer::pdf of the reference (src/objects.rs:259-278) for rays[n][8]; only origin and direction count."""

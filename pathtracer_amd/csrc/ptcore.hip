@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <array>
 #include <deque>
+#include <mutex>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -195,6 +196,8 @@ static int grid_fixed(const pt_context *ctx, uint64_t upper_bound, int blocks_pe
     return (int)((blocks + 7) / 8 * 8);  // the same number of workgroups on every XCD
 }
 
+static hipError_t scratch_lookup(int device);
+
 static void free_roll(pt_context *ctx, pt_context::Roll &r) {
     free_pool(ctx, r.allocs);
     r.n_regions = r.cap = 0;
@@ -325,6 +328,10 @@ int pt_create(int device, pt_context **out) {
     }
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = scratch_lookup(device)) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, PT_ERR_HIP, "hipGetSymbolAddress of the static scratch array on device %d: %s", device, hipGetErrorString(e));
+    }
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -1524,6 +1531,89 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
     return sync_all(ctx);
+}
+
+// ---------------------------------------------------------------- first hits without allocating
+// pt_trace_first_hit_static: the closest-hit query for callers that must not allocate.  What
+// pt_trace_first_hit takes from the context's path state (rays, hits, the ray queue, its control
+// words, the part of the traversal stacks that does not fit LDS) lives in one file-scope device
+// array instead.  Every GPU holds its own copy of that array at its own address: the address is
+// looked up once per device, with that device current, and from then on only that address is used
+// on the host side (the array's name is not a device address in host code).
+constexpr uint32_t STATIC_MAX_RAYS = PT_STATIC_TRACE_MAX_RAYS;
+constexpr uint32_t STATIC_BLOCKS = 128;                       // workgroups of its launches: the stack overflow is [level][lane of the launch]
+constexpr uint32_t STATIC_STACK_LEVELS = 2 * 64 + 4;          // deepest stack a scene that passes nodes_ok can need (world + instanced set)
+constexpr uint32_t STATIC_EXTRA_LEVELS = STATIC_STACK_LEVELS > (uint32_t)LDS_LEVELS ? STATIC_STACK_LEVELS - LDS_LEVELS : 0u;
+constexpr size_t STATIC_QUEUE_ENTRIES = ((size_t)STATIC_MAX_RAYS + QUEUE_CHUNK - 1) / QUEUE_CHUNK * QUEUE_CHUNK;
+constexpr size_t STATIC_OFF_RAY_O = 0;
+constexpr size_t STATIC_OFF_RAY_D = STATIC_OFF_RAY_O + (size_t)STATIC_MAX_RAYS * sizeof(float4);
+constexpr size_t STATIC_OFF_HIT = STATIC_OFF_RAY_D + (size_t)STATIC_MAX_RAYS * sizeof(float4);
+constexpr size_t STATIC_OFF_HIT2 = STATIC_OFF_HIT + (size_t)STATIC_MAX_RAYS * sizeof(float4);
+constexpr size_t STATIC_OFF_QUEUE = STATIC_OFF_HIT2 + (size_t)STATIC_MAX_RAYS * sizeof(uint32_t);
+constexpr size_t STATIC_OFF_CTL = STATIC_OFF_QUEUE + STATIC_QUEUE_ENTRIES * sizeof(uint32_t);
+constexpr size_t STATIC_OFF_OVERFLOW = (STATIC_OFF_CTL + (size_t)CTL_WORDS * sizeof(uint32_t) + 255) / 256 * 256;
+constexpr size_t STATIC_BYTES = STATIC_OFF_OVERFLOW + (size_t)STATIC_EXTRA_LEVELS * STATIC_BLOCKS * BLOCK * sizeof(uint2);
+static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
+
+constexpr int STATIC_MAX_DEVICES = 64;
+static unsigned char *g_scratch_ptr[STATIC_MAX_DEVICES];  // device address of `scratch` on each GPU seen so far
+
+// Called by pt_create with `device` current.
+static hipError_t scratch_lookup(int device) {
+    if (device < 0 || device >= STATIC_MAX_DEVICES) return hipSuccess;  // such a device has no static first-hit query
+    static std::mutex m;
+    std::lock_guard<std::mutex> lock(m);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = (unsigned char *)p;
+    return hipSuccess;
+}
+
+int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_t n, pt_hit *out_device) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "upload a scene before tracing");
+    if (n == 0) return PT_OK;
+    if (!rays_device || !out_device) return fail(ctx, PT_ERR_INVALID, "NULL ray or output array");
+    if (n > STATIC_MAX_RAYS)
+        return fail(ctx, PT_ERR_INVALID, "pt_trace_first_hit_static takes at most %u rays per call (got %llu): split the call, or use pt_trace_first_hit",
+                    STATIC_MAX_RAYS, (unsigned long long)n);
+    if (ctx->stack_need > STATIC_STACK_LEVELS) return fail(ctx, PT_ERR_UNSUPPORTED, "the scene's BVHs are deeper than the static traversal stacks");
+    unsigned char *base = ctx->device < STATIC_MAX_DEVICES ? g_scratch_ptr[ctx->device] : nullptr;
+    if (!base) return fail(ctx, PT_ERR_STATE, "no static scratch on device %d", ctx->device);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    PathState ps{};
+    ps.ray_o = (float4 *)(base + STATIC_OFF_RAY_O);
+    ps.ray_d = (float4 *)(base + STATIC_OFF_RAY_D);
+    ps.hit = (float4 *)(base + STATIC_OFF_HIT);
+    ps.hit2 = (uint32_t *)(base + STATIC_OFF_HIT2);
+    ps.ray_queue[0] = (uint32_t *)(base + STATIC_OFF_QUEUE);
+    ps.ctl = (uint32_t *)(base + STATIC_OFF_CTL);
+    ps.overflow = (uint2 *)(base + STATIC_OFF_OVERFLOW);
+    ps.overflow_stride = STATIC_BLOCKS * BLOCK;
+    ps.max_chunks = (uint32_t)(STATIC_QUEUE_ENTRIES / QUEUE_CHUNK);
+    ps.n_slots = (uint32_t)n;
+    ps.refill_below = ctx->refill_below;
+    ps.leaf_batch = ctx->leaf_batch;
+    hipStream_t st = ctx->stream;
+    // the array keeps what the last call on this GPU left in it: the control words start from zero
+    HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, (size_t)CTL_WORDS * sizeof(uint32_t), st));
+    const uint64_t want = (n + BLOCK - 1) / BLOCK;
+    const dim3 g((uint32_t)std::min<uint64_t>(want, STATIC_BLOCKS)), b(BLOCK);
+    hipLaunchKernelGGL(k_load_rays, g, b, 0, st, rays_device, ps, (uint32_t)n);
+    const bool insts = ctx->scene.world.insts.prim_count != 0;
+    if (ctx->use_wide()) {
+        if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, ps, (uint32_t)n, ctx->stats);
+        else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, ps, (uint32_t)n, ctx->stats);
+    } else {
+        hipLaunchKernelGGL(k_trace, g, b, 0, st, ctx->scene, ps, (uint32_t)n);
+        if (insts) hipLaunchKernelGGL(k_trace_inst, g, b, 0, st, ctx->scene, ps, (uint32_t)n);
+    }
+    hipLaunchKernelGGL(k_trace_out, g, b, 0, st, ctx->scene, ps, (uint32_t)n, out_device);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipGetLastError());
+    return PT_OK;
 }
 
 int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_solid_angle, float *out) {
