@@ -246,6 +246,32 @@ int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_
  * PT_OPT_INTEGRATOR = 1 uses it. */
 int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_solid_angle, float *out);
 
+/* The Material trait of one material at caller-supplied shading points (src/materials.rs:80-123), for checking
+ * the device's shading arithmetic call by call: scatter with the generator keyed by (seed, pixel, stratum) as
+ * pt_render keys it, starting at its first draw; bsdf_evaluate and scattering_pdf at the scattered direction
+ * and at the caller's w_in; emitted.  Vectors are in the local shading frame (y = surface normal); u, v, p and
+ * front_face stand for the HitRecord fields the materials read (src/objects.rs:14-27).  in[n], out[n] are host
+ * memory.  No counterpart in the reference, whose materials are reached through Arc<dyn Material>. */
+typedef struct pt_material_probe_in {
+    float w_out[3];
+    float u, v;
+    float p[3];
+    uint32_t front_face;
+    uint32_t pixel, stratum;
+    float w_in[3];
+} pt_material_probe_in;
+typedef struct pt_material_probe_out {
+    float w_in[3];       /* Material::scatter */
+    uint32_t draws;      /* random numbers it consumed */
+    float bsdf[3];       /* bsdf_evaluate(w_out, scattered w_in) */
+    float pdf;           /* scattering_pdf(w_out, scattered w_in) */
+    float bsdf_at[3];    /* bsdf_evaluate(w_out, in.w_in) */
+    float pdf_at;        /* scattering_pdf(w_out, in.w_in) */
+    float emitted[3];    /* Material::emitted */
+    uint32_t reserved;
+} pt_material_probe_out;
+int pt_material_probe(pt_context *ctx, int32_t material, uint64_t seed, const pt_material_probe_in *in, uint64_t n, pt_material_probe_out *out);
+
 /* Accumulator: W*H*3 f32 sums, row-major (i = u + v*W, src/camera.rs:202-205), and the pass count. */
 int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples);
 /* (sum / n_samples).to_rgb() per pixel (src/camera.rs:221-226, src/types/color.rs:68-78). */

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <thread>
 
+#include "../include/ptcore.h"
 #include "render.hpp"
 
 using namespace oracle;
@@ -301,6 +302,33 @@ uint32_t pto_material_scatter(const pto_scene *s, int32_t mat, const float *w_ou
     V3 w = s->sc->shading.scatter(*m, rng, v3(w_out[0], w_out[1], w_out[2]), rec);
     w_in3[0] = w.x; w_in3[1] = w.y; w_in3[2] = w.z;
     return rng.counter;
+}
+// The same per probe as pt_material_probe of include/ptcore.h (whose structs these are): scatter, then
+// bsdf_evaluate / scattering_pdf at the scattered direction and at in.w_in, and emitted.
+void pto_material_probe(const pto_scene *s, int32_t mat, uint64_t seed, const pt_material_probe_in *in, uint64_t n, pt_material_probe_out *out) {
+    const Material *m = s->sc->mat(mat);
+    const Shading &sh = s->sc->shading;
+    for (uint64_t i = 0; i < n; i++) {
+        const pt_material_probe_in &pi = in[i];
+        HitRecord rec;
+        rec.u = pi.u; rec.v = pi.v;
+        rec.p = v3(pi.p[0], pi.p[1], pi.p[2]);
+        rec.front_face = pi.front_face != 0;
+        rec.normal = v3(0, 1, 0); rec.t = 1.0f; rec.material = mat;
+        const V3 wo = v3(pi.w_out[0], pi.w_out[1], pi.w_out[2]), wa = v3(pi.w_in[0], pi.w_in[1], pi.w_in[2]);
+        Rng rng = Rng::for_sample(seed, pi.pixel, pi.stratum);
+        V3 wi = sh.scatter(*m, rng, wo, rec);
+        pt_material_probe_out &o = out[i];
+        o.w_in[0] = wi.x; o.w_in[1] = wi.y; o.w_in[2] = wi.z;
+        o.draws = rng.counter;
+        Color f = sh.bsdf_evaluate(*m, wo, wi, rec), fa = sh.bsdf_evaluate(*m, wo, wa, rec), e = sh.emitted(*m, rec);
+        o.bsdf[0] = f.x; o.bsdf[1] = f.y; o.bsdf[2] = f.z;
+        o.pdf = sh.scattering_pdf(*m, wo, wi, rec);
+        o.bsdf_at[0] = fa.x; o.bsdf_at[1] = fa.y; o.bsdf_at[2] = fa.z;
+        o.pdf_at = sh.scattering_pdf(*m, wo, wa, rec);
+        o.emitted[0] = e.x; o.emitted[1] = e.y; o.emitted[2] = e.z;
+        o.reserved = 0;
+    }
 }
 void pto_texture_value(const pto_scene *s, int32_t tex, float u, float v, float *out3) {
     Color c = s->sc->textures.value(tex, u, v, v3(0, 0, 0));

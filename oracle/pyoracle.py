@@ -59,6 +59,8 @@ def lib() -> C.CDLL:
         L.pto_material_scatter.restype = C.c_uint32
         L.pto_material_scatter.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                            C.c_uint32, C.c_void_p]
+        L.pto_material_probe.restype = None
+        L.pto_material_probe.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
         L.pto_texture_value.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p]
         L.pto_light_pdf.restype = C.c_float
         L.pto_light_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -200,6 +202,14 @@ class OracleScene:
         w = np.zeros(3, np.float32)
         n = lib().pto_material_scatter(self.h, mat, _p(_f3(w_out)), _p(rec), seed, pixel, stratum, _p(w))
         return w, n
+
+    def material_probe(self, mat: int, probes: np.ndarray, seed: int = 0) -> np.ndarray:
+        """The oracle's side of pt_material_probe: probes[n] and the result use the structs of include/ptcore.h."""
+        from pathtracer_amd.core import PROBE_IN_DTYPE, PROBE_OUT_DTYPE  # layouts only
+        probes = np.ascontiguousarray(probes, PROBE_IN_DTYPE)
+        out = np.zeros(probes.shape[0], PROBE_OUT_DTYPE)
+        lib().pto_material_probe(self.h, mat, seed, _p(probes), probes.shape[0], _p(out))
+        return out
 
     def texture_value(self, tex: int, u: float, v: float) -> np.ndarray:
         out = np.zeros(3, np.float32)

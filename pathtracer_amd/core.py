@@ -86,9 +86,14 @@ class pt_stats(C.Structure):
 PT_PRIM_TRI, PT_PRIM_SPHERE, PT_PRIM_QUAD = 0, 1, 2  # pt_hit::prim_type
 HIT_DTYPE = np.dtype([("prim_type", np.int32), ("prim_id", np.int32), ("inst_id", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
 
+PROBE_IN_DTYPE = np.dtype([("w_out", np.float32, 3), ("u", np.float32), ("v", np.float32), ("p", np.float32, 3), ("front_face", np.uint32),
+                           ("pixel", np.uint32), ("stratum", np.uint32), ("w_in", np.float32, 3)])  # pt_material_probe_in
+PROBE_OUT_DTYPE = np.dtype([("w_in", np.float32, 3), ("draws", np.uint32), ("bsdf", np.float32, 3), ("pdf", np.float32), ("bsdf_at", np.float32, 3),
+                            ("pdf_at", np.float32), ("emitted", np.float32, 3), ("reserved", np.uint32)])  # pt_material_probe_out
+
 # every symbol include/ptcore.h and include/pthost.h declare
 CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
-                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_trace_first_hit_static", "pt_light_pdf", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
+                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_trace_first_hit_static", "pt_light_pdf", "pt_material_probe", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
                 "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
 HOST_SYMBOLS = ["pth_scene_build", "pth_scene_build_opts", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
                 "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles"]
@@ -115,6 +120,7 @@ def core_lib() -> C.CDLL:
         L.pt_trace_first_hit.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_trace_first_hit_static.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_light_pdf.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
+        L.pt_material_probe.argtypes = [vp, C.c_int32, C.c_uint64, vp, C.c_uint64, vp]
         L.pt_read_accum.argtypes = [vp, vp, vp]
         L.pt_read_rgb8.argtypes = [vp, vp]
         L.pt_read_triangle_order.argtypes = [vp, vp, C.c_uint32]
@@ -336,6 +342,13 @@ class Renderer:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         out = np.zeros(rays.shape[0], np.float32)
         self._check(self.L.pt_light_pdf(self.ctx, rays.ctypes.data_as(C.c_void_p), rays.shape[0], int(tris_by_solid_angle), out.ctypes.data_as(C.c_void_p)), "pt_light_pdf")
+        return out
+
+    def material_probe(self, material: int, probes: np.ndarray, seed: int = 0) -> np.ndarray:
+        """pt_material_probe: scatter / bsdf_evaluate / scattering_pdf / emitted of one material at probes[n] (PROBE_IN_DTYPE)."""
+        probes = np.ascontiguousarray(probes, PROBE_IN_DTYPE)
+        out = np.zeros(probes.shape[0], PROBE_OUT_DTYPE)
+        self._check(self.L.pt_material_probe(self.ctx, material, seed, probes.ctypes.data_as(C.c_void_p), probes.shape[0], out.ctypes.data_as(C.c_void_p)), "pt_material_probe")
         return out
 
     def read_accum(self):

@@ -817,6 +817,60 @@ __global__ __launch_bounds__(BLOCK) void k_trace_out(DevScene sc, PathState ps, 
     }
 }
 
+// The Material trait of one material at caller-supplied shading points (pt_material_probe): the functions
+// the shading kernels call, one probe per lane.
+template <int MT>
+__device__ __forceinline__ void probe_material(const DevScene &sc, const DevMaterial &m, uint64_t seed_mixed, const pt_material_probe_in &in,
+                                               pt_material_probe_out &out) {
+    Surf s;
+    s.p = mk3(in.p[0], in.p[1], in.p[2]);
+    s.normal = mk3(0.0f, 1.0f, 0.0f);
+    s.t = 1.0f;
+    s.front_face = in.front_face != 0u;
+    s.material = 0;
+    s.u = in.u;
+    s.v = in.v;
+    const f3 w_out = mk3(in.w_out[0], in.w_out[1], in.w_out[2]), w_at = mk3(in.w_in[0], in.w_in[1], in.w_in[2]);
+    Rng rng;
+    rng.init(seed_mixed, in.pixel, in.stratum, 0u);
+    f3 w_in = mk3(0.0f, 0.0f, 0.0f), e = mk3(0.0f, 0.0f, 0.0f);
+    if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
+        if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v, s.p);  // Diffuse::emitted, light.rs:42-47
+    } else {
+        w_in = mat_scatter<MT>(sc, m, rng, w_out, s);
+    }
+    const f3 f = mat_eval<MT>(sc, m, w_out, w_in, s), f_at = mat_eval<MT>(sc, m, w_out, w_at, s);
+    out.w_in[0] = w_in.x; out.w_in[1] = w_in.y; out.w_in[2] = w_in.z;
+    out.draws = rng.counter;
+    out.bsdf[0] = f.x; out.bsdf[1] = f.y; out.bsdf[2] = f.z;
+    out.pdf = mat_pdf<MT>(m, w_out, w_in, s);
+    out.bsdf_at[0] = f_at.x; out.bsdf_at[1] = f_at.y; out.bsdf_at[2] = f_at.z;
+    out.pdf_at = mat_pdf<MT>(m, w_out, w_at, s);
+    out.emitted[0] = e.x; out.emitted[1] = e.y; out.emitted[2] = e.z;
+    out.reserved = 0u;
+}
+__global__ __launch_bounds__(BLOCK) void k_material_probe(DevScene sc, uint32_t material, uint64_t seed_mixed, const pt_material_probe_in *in, uint32_t n,
+                                                          pt_material_probe_out *out) {
+    const DevMaterial m = sc.mats[material];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const pt_material_probe_in pi = in[i];
+        pt_material_probe_out po;
+        switch (m.type) {
+            case PTS_MAT_LAMBERTIAN: probe_material<PTS_MAT_LAMBERTIAN>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_METAL: probe_material<PTS_MAT_METAL>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DIELECTRIC: probe_material<PTS_MAT_DIELECTRIC>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DIFFUSE_LIGHT: probe_material<PTS_MAT_DIFFUSE_LIGHT>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DISNEY: probe_material<PTS_MAT_DISNEY>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DISNEY_DIFFUSE: probe_material<PTS_MAT_DISNEY_DIFFUSE>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DISNEY_METAL: probe_material<PTS_MAT_DISNEY_METAL>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DISNEY_GLASS: probe_material<PTS_MAT_DISNEY_GLASS>(sc, m, seed_mixed, pi, po); break;
+            case PTS_MAT_DISNEY_CLEARCOAT: probe_material<PTS_MAT_DISNEY_CLEARCOAT>(sc, m, seed_mixed, pi, po); break;
+            default: probe_material<PTS_MAT_DISNEY_SHEEN>(sc, m, seed_mixed, pi, po); break;
+        }
+        out[i] = po;
+    }
+}
+
 // LightBuffer::pdf for caller-supplied rays (origin and direction of rays[i][8]).
 __global__ __launch_bounds__(BLOCK) void k_light_pdf(DevScene sc, const float *rays, uint32_t n, int tris_by_solid_angle, float *out) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {

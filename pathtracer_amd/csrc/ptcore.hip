@@ -1645,6 +1645,36 @@ int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_sol
     return PT_OK;
 }
 
+int pt_material_probe(pt_context *ctx, int32_t material, uint64_t seed, const pt_material_probe_in *in, uint64_t n, pt_material_probe_out *out) {
+    if (!ctx) return PT_ERR_INVALID;
+    if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "upload a scene before probing its materials");
+    if (material < 0 || (uint32_t)material >= ctx->scene.n_materials) return fail(ctx, PT_ERR_INVALID, "material %d out of range (the scene has %u)", material, ctx->scene.n_materials);
+    if (n == 0) return PT_OK;
+    if (!in || !out) return fail(ctx, PT_ERR_INVALID, "NULL probe or output array");
+    if (n > (1ull << 28)) return fail(ctx, PT_ERR_INVALID, "too many probes in one call");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    pt_material_probe_in *d_in = nullptr;
+    pt_material_probe_out *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_in, n * sizeof *d_in);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof *d_out);
+    if (e != hipSuccess) {
+        if (d_in) (void)hipFree(d_in);
+        return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    hipStream_t st = ctx->stream;
+    e = hipMemcpyAsync(d_in, in, n * sizeof *d_in, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_material_probe, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, ctx->scene, (uint32_t)material, mix64_host(seed), d_in, (uint32_t)n, d_out);
+        e = hipMemcpyAsync(out, d_out, n * sizeof *d_out, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_material_probe: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
 int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples) {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
