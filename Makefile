@@ -9,14 +9,14 @@ ARCH ?= gfx950
 HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -shared -std=c++17 -Wall
 HOSTFLAGS = -O2 -ffp-contract=off -fno-fast-math -fPIC -shared -std=c++17 -Wall -Wextra -pthread
 
-CORE_SRC = pathtracer_amd/csrc/ptcore.hip pathtracer_amd/csrc/bvh_build.hip
+CORE_SRC = pathtracer_amd/csrc/ptcore.hip pathtracer_amd/csrc/bvh_build.hip pathtracer_amd/csrc/ptgroup.hip
 CORE_DEP = $(wildcard pathtracer_amd/csrc/*.h) include/ptcore.h include/ptscene_src.h
 HOST_DEP = pathtracer_amd/host/pthost.hpp include/pthost.h include/ptcore.h include/ptscene_src.h
 
 all: pathtracer_amd/libptcore.so pathtracer_amd/libpthost.so pathtracer_amd/ptrender oracle
 
 pathtracer_amd/libptcore.so: $(CORE_SRC) $(CORE_DEP)
-	$(HIPCC) $(HIPFLAGS) -o $@ $(CORE_SRC)
+	$(HIPCC) $(HIPFLAGS) -o $@ $(CORE_SRC) -ldl
 
 pathtracer_amd/libpthost.so: pathtracer_amd/host/pthost.cpp pathtracer_amd/host/objload.cpp $(HOST_DEP) pathtracer_amd/libptcore.so
 	$(CXX) $(HOSTFLAGS) -o $@ pathtracer_amd/host/pthost.cpp pathtracer_amd/host/objload.cpp -Lpathtracer_amd -lptcore -Wl,-rpath,'$$ORIGIN'
@@ -35,7 +35,7 @@ clean:
 
 # The same library with every scene reference checked before use (PTCORE_LIB=... selects it in the Python binding).
 pathtracer_amd/libptcore_check.so: $(CORE_SRC) $(CORE_DEP)
-	$(HIPCC) $(HIPFLAGS) -DPT_BOUNDS_CHECK -o $@ $(CORE_SRC)
+	$(HIPCC) $(HIPFLAGS) -DPT_BOUNDS_CHECK -o $@ $(CORE_SRC) -ldl
 check-lib: pathtracer_amd/libptcore_check.so
 
 # Register / LDS / scratch use of every kernel (no output file).

@@ -128,8 +128,9 @@ def main():
     span = (hi - lo) - S + 1  # first strata a step may start at; long runs wrap around inside the shard
 
     def step(k):
+        # a run longer than the shard starts over inside it with another seed: no (seed, pixel, stratum) sample is drawn twice
         b = lo + (k * S) % span
-        r.render(b, b + S, seed=1)
+        r.render(b, b + S, seed=1 + (k * S) // span)
 
     for k in range(args.warmup):
         step(k)

@@ -289,6 +289,37 @@ int pt_set_accum_from_device(pt_context *ctx, const void *src_device, uint32_t n
 int pt_stats_get(pt_context *ctx, pt_stats *out);
 int pt_stats_reset(pt_context *ctx);
 
+/* ---- several GPUs of one node behind one handle ------------------------------------------------------------
+ * Camera::render (src/camera.rs:162-167) is one call; a group keeps it one call when the work is spread over
+ * GPUs.  Every member (one pt_context per listed device) holds the whole scene; pt_group_render cuts its
+ * stratum range into contiguous pieces, one per member (pt_group_split), and each member enqueues its piece
+ * from a host thread of its own; the passes are independent given the (seed, pixel, stratum) generator
+ * (src/camera.rs:185-198).  Readers sum the members' accumulators (src/camera.rs:172-173, :216) onto the first
+ * device with one RCCL ncclReduce (sum, f32, W*H*3 values) and add up the pass counts (src/camera.rs:199); f32
+ * sums are re-associated, so a group's image equals one context's to rounding, not bits.  Rendering may go on
+ * after a read: the members' own accumulators are left as they are.  A group that lists a device more than once
+ * is summed with copies instead of RCCL (for rehearsing the split on one GPU).  librccl.so is opened when a
+ * group is created, not when libptcore is loaded.  One group is not re-entrant. */
+typedef struct pt_group pt_group;
+int pt_group_create(const int *devices, int n, pt_group **out);
+void pt_group_destroy(pt_group *g);
+const char *pt_group_last_error(const pt_group *g); /* g may be NULL: error of the last failed pt_group_create */
+int pt_group_size(const pt_group *g);
+pt_context *pt_group_member(pt_group *g, int i);    /* for per-GPU queries (pt_stats_get, pt_trace_first_hit, ...) */
+/* The piece [*begin_i, *end_i) of [stratum_begin, stratum_end) that member i of n renders: contiguous, sizes
+ * differ by at most one, larger pieces first.  A pure function (no GPU needed). */
+void pt_group_split(uint32_t stratum_begin, uint32_t stratum_end, int n, int i, uint32_t *begin_i, uint32_t *end_i);
+int pt_group_set_option(pt_group *g, int key, double value);
+int pt_group_upload_scene(pt_group *g, const pt_scene_desc *scene);
+int pt_group_set_camera(pt_group *g, const pt_camera_desc *camera);
+int pt_group_render(pt_group *g, uint32_t stratum_begin, uint32_t stratum_end, uint64_t seed);
+int pt_group_sync(pt_group *g);
+int pt_group_read_accum(pt_group *g, float *rgb_sum, uint32_t *n_samples);
+int pt_group_read_rgb8(pt_group *g, uint8_t *rgb);
+int pt_group_reset_accum(pt_group *g);
+int pt_group_stats_get(pt_group *g, pt_stats *out); /* counts summed over the members, times of the slowest */
+int pt_group_stats_reset(pt_group *g);
+
 #ifdef __cplusplus
 }
 #endif

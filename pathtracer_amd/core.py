@@ -94,7 +94,10 @@ PROBE_OUT_DTYPE = np.dtype([("w_in", np.float32, 3), ("draws", np.uint32), ("bsd
 # every symbol include/ptcore.h and include/pthost.h declare
 CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
                 "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_trace_first_hit_static", "pt_light_pdf", "pt_material_probe", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
-                "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset"]
+                "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset",
+                "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_member", "pt_group_split", "pt_group_set_option",
+                "pt_group_upload_scene", "pt_group_set_camera", "pt_group_render", "pt_group_sync", "pt_group_read_accum", "pt_group_read_rgb8",
+                "pt_group_reset_accum", "pt_group_stats_get", "pt_group_stats_reset"]
 HOST_SYMBOLS = ["pth_scene_build", "pth_scene_build_opts", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
                 "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles"]
 
@@ -129,6 +132,26 @@ def core_lib() -> C.CDLL:
         L.pt_set_accum_from_device.argtypes = [vp, vp, C.c_uint32]
         L.pt_stats_get.argtypes = [vp, vp]
         L.pt_stats_reset.argtypes = [vp]
+        L.pt_group_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+        L.pt_group_destroy.argtypes = [vp]
+        L.pt_group_destroy.restype = None
+        L.pt_group_last_error.argtypes = [vp]
+        L.pt_group_last_error.restype = C.c_char_p
+        L.pt_group_size.argtypes = [vp]
+        L.pt_group_member.argtypes = [vp, C.c_int]
+        L.pt_group_member.restype = vp
+        L.pt_group_split.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pt_group_split.restype = None
+        L.pt_group_set_option.argtypes = [vp, C.c_int, C.c_double]
+        L.pt_group_upload_scene.argtypes = [vp, vp]
+        L.pt_group_set_camera.argtypes = [vp, vp]
+        L.pt_group_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.pt_group_sync.argtypes = [vp]
+        L.pt_group_read_accum.argtypes = [vp, vp, vp]
+        L.pt_group_read_rgb8.argtypes = [vp, vp]
+        L.pt_group_reset_accum.argtypes = [vp]
+        L.pt_group_stats_get.argtypes = [vp, vp]
+        L.pt_group_stats_reset.argtypes = [vp]
         _core = L
     return _core
 
@@ -378,3 +401,75 @@ class Renderer:
 
     def stats_reset(self):
         self._check(self.L.pt_stats_reset(self.ctx), "pt_stats_reset")
+
+
+def group_split(stratum_begin: int, stratum_end: int, n: int, i: int):
+    """pt_group_split: the piece of [stratum_begin, stratum_end) that member i of n renders (no GPU needed)."""
+    b, e = C.c_uint32(0), C.c_uint32(0)
+    core_lib().pt_group_split(stratum_begin, stratum_end, n, i, C.byref(b), C.byref(e))
+    return int(b.value), int(e.value)
+
+
+class GroupRenderer:
+    """One ``pt_group``: the same scene on several GPUs of this node, strata split between them, one reduce on reading."""
+
+    def __init__(self, scene: HostScene, devices):
+        self.scene = scene
+        self.L = core_lib()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        if self.L.pt_group_create(devs, len(devices), C.byref(h)):
+            raise PtError("pt_group_create: " + self.L.pt_group_last_error(None).decode())
+        self.g = h
+        if getattr(scene, "device_bvh_from", 0):
+            self.set_option(PT_OPT_DEVICE_BVH, scene.device_bvh_from)
+        self._check(self.L.pt_group_upload_scene(self.g, C.byref(scene.desc)), "pt_group_upload_scene")
+        self._check(self.L.pt_group_set_camera(self.g, C.byref(scene.camera)), "pt_group_set_camera")
+        self.width, self.height, self.sqrt_spp = scene.width, scene.height, scene.sqrt_spp
+        self.npix = self.width * self.height
+
+    def _check(self, rc: int, what: str):
+        if rc:
+            raise PtError(f"{what} failed ({rc}): " + self.L.pt_group_last_error(self.g).decode())
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.pt_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        self.close()
+
+    def size(self) -> int:
+        return self.L.pt_group_size(self.g)
+
+    def set_option(self, key: int, value: float):
+        self._check(self.L.pt_group_set_option(self.g, key, float(value)), "pt_group_set_option")
+
+    def render(self, stratum_begin: int, stratum_end: int, seed: int = 0):
+        self._check(self.L.pt_group_render(self.g, stratum_begin, stratum_end, seed), "pt_group_render")
+
+    def sync(self):
+        self._check(self.L.pt_group_sync(self.g), "pt_group_sync")
+
+    def read_accum(self):
+        acc = np.zeros((self.npix, 3), np.float32)
+        n = C.c_uint32(0)
+        self._check(self.L.pt_group_read_accum(self.g, acc.ctypes.data_as(C.c_void_p), C.byref(n)), "pt_group_read_accum")
+        return acc, int(n.value)
+
+    def read_rgb8(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        self._check(self.L.pt_group_read_rgb8(self.g, out.ctypes.data_as(C.c_void_p)), "pt_group_read_rgb8")
+        return out
+
+    def reset_accum(self):
+        self._check(self.L.pt_group_reset_accum(self.g), "pt_group_reset_accum")
+
+    def stats(self) -> dict:
+        s = pt_stats()
+        self._check(self.L.pt_group_stats_get(self.g, C.byref(s)), "pt_group_stats_get")
+        return {k: getattr(s, k) for k, _ in pt_stats._fields_}
+
+    def stats_reset(self):
+        self._check(self.L.pt_group_stats_reset(self.g), "pt_group_stats_reset")

@@ -23,7 +23,8 @@ struct TriBvhResult {
 
 // tri_hot / tri_cold / tri_mat: the slices of the scene arrays that belong to the buffer (n
 // triangles); they are reordered in place.  wide: room for 4 * (n - 1) float4.  order (device, n
-// entries, may be null): order[i] = position before the build of the triangle now at position i.
+// entries, may be null): what the caller calls each triangle (e.g. its index in the scene-wide arrays);
+// permuted like the triangles, so order[i] afterwards names the triangle now at position i.
 // Everything runs on `stream`; the call returns after the stream has finished.
 int build_tri_bvh_device(hipStream_t stream, float4 *tri_hot, float4 *tri_cold, int32_t *tri_mat, uint32_t n, float4 *wide, uint32_t *order,
                          TriBvhResult *out, std::string &err);

@@ -369,7 +369,12 @@ int build_tri_bvh_device(hipStream_t stream, float4 *tri_hot, float4 *tri_cold, 
         BUILD_TRY(hipMemcpyAsync(tri_hot, hot2, 3 * (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, stream));
         BUILD_TRY(hipMemcpyAsync(tri_cold, cold2, 6 * (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, stream));
         BUILD_TRY(hipMemcpyAsync(tri_mat, mat2, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-        if (order) BUILD_TRY(hipMemcpyAsync(order, ids, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        if (order) {  // the caller's names of the triangles move with them
+            uint32_t *order2;
+            BUILD_TRY(tmp.get(&order2, (size_t)n));
+            hipLaunchKernelGGL((k_gather<uint32_t, 1>), dim3(grid_n), dim3(BB), 0, stream, order, order2, ids, n);
+            BUILD_TRY(hipMemcpyAsync(order, order2, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+        }
         BUILD_TRY(hipStreamSynchronize(stream));
     }
     BUILD_TRY(hipGetLastError());

@@ -17,6 +17,7 @@ struct DevStats {
     // PT_BOUNDS_CHECK build only: [0] out-of-range references caught, [1] lanes that gave up after too
     // many passes, [2..7] state of the first such lane
     unsigned long long bad_refs[8];
+    unsigned long long queue_overflow;  // queue entries dropped for want of room (wave_push)
 };
 
 struct BatchParams {
@@ -183,7 +184,7 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
         WavePush w;
         w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[0]);
         w.fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[1]);
-        wave_push(w, mine, slot, ps.shade_queue[q], &ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE]);
+        wave_push(w, mine, slot, ps.shade_queue[q], &ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE], ps.max_chunks, ps.queue_overflow);
         if (lane_id() == 0u) {
             state[0] = w.chunk;
             state[1] = w.fill;
@@ -220,7 +221,7 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 template <bool COUNT, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     extend_prologue(ps, bounce, n_chunks, stats);
     if (CLASSIFY) shade_push_init();
     LaneStack st;
@@ -263,7 +264,7 @@ template <bool INSTANCES, bool MOVING>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, uint32_t new_base,
                                                                       uint32_t n_new, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     extend_prologue(ps, bounce, n_chunks + n_new, stats);
     const uint32_t queued = n_chunks * QUEUE_CHUNK;
     const uint32_t n_pieces = queued / 64u + (n_new + 63u) / 64u;
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
     // a path ends at an emitter (src/camera.rs:288-290), unless a medium scatters it on its way there
     constexpr bool CONTINUES = MT != PTS_MAT_DIFFUSE_LIGHT || MEDIA;
     const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE];
+    const uint32_t n_chunks = min(ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE], ps.max_chunks);
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
     const uint32_t *queue = ps.shade_queue[q];
     WavePush out, shadows;
@@ -567,10 +568,10 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
         }
         if constexpr (CONTINUES) {
             survivors += (uint32_t)__popcll(__ballot(alive));
-            wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE]);
+            wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE], ps.max_ray_chunks, ps.queue_overflow);
             if constexpr (NEE) {
                 survivors += (uint32_t)__popcll(__ballot(shadow));
-                wave_push(shadows, shadow, slot, ps.shadow_queue, &ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE]);
+                wave_push(shadows, shadow, slot, ps.shadow_queue, &ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks, ps.queue_overflow);
             }
         }
     }
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
 template <bool INSTANCES>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE];
+    const uint32_t n_chunks = min(ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the shading of the next step
         ps.ctl[(CTL_SHADOW_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
         ps.ctl[(CTL_SHADOW_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene s
 // per-bounce kernels call, so every path gets the same arithmetic.
 __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, f3 background, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE];
+    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};

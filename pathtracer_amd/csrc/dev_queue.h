@@ -22,9 +22,13 @@ __device__ __forceinline__ void wave_push_close(const WavePush &w, uint32_t *ent
 }
 
 // Appends `id` for every lane with want == true.  All 64 lanes of the wave must call it
-// together.  `n_chunks` is the queue's chunk count; the caller guarantees capacity (the
-// host sizes every queue for the worst case: paths / (QUEUE_CHUNK - 63) + producing waves).
-__device__ __forceinline__ void wave_push(WavePush &w, bool want, uint32_t id, uint32_t *entries, uint32_t *n_chunks) {
+// together.  `n_chunks` is the queue's chunk count.  The host sizes every queue for the worst
+// case (paths / (QUEUE_CHUNK - 63) + one open chunk per producing wave of every launch that
+// fills it); should a queue still run out of its `max_chunks` chunks, the push is dropped and
+// counted in *overflowed, which the next synchronising call reports as an error, instead of
+// writing past the end of the array.
+__device__ __forceinline__ void wave_push(WavePush &w, bool want, uint32_t id, uint32_t *entries, uint32_t *n_chunks, uint32_t max_chunks,
+                                          unsigned long long *overflowed) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;
     const uint32_t k = (uint32_t)__popcll(mask);
@@ -34,6 +38,12 @@ __device__ __forceinline__ void wave_push(WavePush &w, bool want, uint32_t id, u
         if (lane_id() == 0u) got = atomicAdd(n_chunks, 1u);
         w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
         w.fill = 0u;
+        if (w.chunk >= max_chunks) {
+            // consumers walk min(chunk count, max_chunks) chunks, so the count may stay above the capacity
+            if (lane_id() == 0u) atomicAdd(overflowed, (unsigned long long)k);
+            w.chunk = QUEUE_EMPTY;
+            return;
+        }
     }
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (want) entries[(size_t)w.chunk * QUEUE_CHUNK + w.fill + rank] = id;

@@ -142,7 +142,9 @@ struct PathState {
     uint32_t *shade_queue[MAX_QUEUES];  // likewise; only the queues of material types in use exist
     uint32_t *ctl;                      // CTL_WORDS control words
     uint32_t *bounce_rays;              // [BOUNCE_PROFILE_LEN] rays traced at each bounce of the batch ([0] unused)
-    uint32_t max_chunks;
+    uint32_t max_chunks;      // capacity of each material queue, in chunks
+    uint32_t max_ray_chunks;  // capacity of each ray queue and of the shadow-ray queue (several launches fill them)
+    unsigned long long *queue_overflow;  // entries dropped because a queue was full (never, unless the sizing is wrong)
     uint32_t n_queues;
     uint2 *overflow;           // traversal stack levels beyond LDS: [level][overflow_stride]
     uint32_t overflow_stride;  // lanes of the widest traversal launch

@@ -30,6 +30,7 @@
 
 #include "bvh_build.h"
 #include "dev_kernels.h"
+#include "ptcore_internal.h"
 
 // ============================================================================ host side
 
@@ -69,6 +70,7 @@ struct pt_context {
     float *accum = nullptr;
     uint8_t *rgb8 = nullptr;
     uint32_t n_samples = 0;
+    uint64_t film_pixels = 0;  // pixels `accum` and `rgb8` are allocated for (0: none)
 
     // Path state.  A render call is cut into batches of strata, and up to n_pipes batches are
     // in flight at once, each on its own stream with its own path state: the late bounces of
@@ -285,6 +287,14 @@ static int sync_all(pt_context *ctx) {
         ctx->extend_iv.clear();
     }
     HIP_TRY(ctx, hipGetLastError());
+    {
+        unsigned long long dropped = 0;
+        HIP_TRY(ctx, hipMemcpy(&dropped, &ctx->stats->queue_overflow, sizeof dropped, hipMemcpyDeviceToHost));
+        if (dropped) {
+            HIP_TRY(ctx, hipMemset(&ctx->stats->queue_overflow, 0, sizeof dropped));
+            return fail(ctx, PT_ERR_STATE, "a work queue ran out of room and %llu paths were dropped: the image is incomplete", dropped);
+        }
+    }
 #ifdef PT_BOUNDS_CHECK
     unsigned long long bad[8];
     HIP_TRY(ctx, hipMemcpy(bad, ctx->stats->bad_refs, sizeof bad, hipMemcpyDeviceToHost));
@@ -923,15 +933,23 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
     d.background = v(c->background);
     forget_bounce_profile(ctx);
     const uint64_t npix = (uint64_t)d.width * d.height;
-    if (!ctx->have_camera || (uint64_t)ctx->cam.width * ctx->cam.height != npix) {
+    // until buffers of the new size exist and are cleared the context has no camera
+    ctx->have_camera = false;
+    if (ctx->film_pixels != npix) {
         if (ctx->accum) (void)hipFree(ctx->accum);
         if (ctx->rgb8) (void)hipFree(ctx->rgb8);
         ctx->accum = nullptr;
         ctx->rgb8 = nullptr;
+        ctx->device_bytes -= ctx->film_pixels * 15;
+        ctx->film_pixels = 0;
         hipError_t e = hipMalloc((void **)&ctx->accum, npix * 3 * sizeof(float));
-        if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc accumulator: %s", hipGetErrorString(e));
-        e = hipMalloc((void **)&ctx->rgb8, npix * 3);
-        if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc rgb8: %s", hipGetErrorString(e));
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->rgb8, npix * 3);
+        if (e != hipSuccess) {
+            if (ctx->accum) (void)hipFree(ctx->accum);
+            ctx->accum = nullptr;
+            return fail(ctx, PT_ERR_NOMEM, "hipMalloc of the accumulator and image: %s", hipGetErrorString(e));
+        }
+        ctx->film_pixels = npix;
         ctx->device_bytes += npix * 15;
     }
     HIP_TRY(ctx, hipMemset(ctx->accum, 0, npix * 3 * sizeof(float)));
@@ -943,6 +961,16 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
 }
 
 // ---------------------------------------------------------------- path state
+// Queue capacities in chunks for path state of n_slots paths.  A closed chunk holds more than QUEUE_CHUNK - 64
+// entries, and every producing wave of every launch that fills a queue may leave one open chunk behind: a
+// material queue is filled by one closest-hit launch, a ray queue (and the shadow-ray queue) by one shading
+// launch per material type in use.
+static void queue_capacity(const pt_context *ctx, uint64_t n_slots, uint64_t &max_chunks, uint64_t &max_ray_chunks) {
+    const uint64_t max_waves = (uint64_t)ctx->n_cu * std::max({ctx->blocks_per_cu, ctx->shade_blocks_per_cu, 8}) * (BLOCK / 64);
+    max_chunks = n_slots / (QUEUE_CHUNK - 63u) + max_waves + 8u;
+    max_ray_chunks = n_slots / (QUEUE_CHUNK - 63u) + (uint64_t)std::max<uint32_t>(1u, ctx->n_queues) * max_waves + 8u;
+}
+
 static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots) {
     if (n_slots <= pp.capacity) return PT_OK;
     (void)hipStreamSynchronize(pp.stream);
@@ -956,14 +984,14 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit, n_slots))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit2, n_slots))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.contrib, n_slots))) return rc;
-    // queue capacity: a closed chunk holds more than QUEUE_CHUNK - 64 entries, and every wave of
-    // the largest launch may leave one open chunk behind
-    const uint64_t max_waves = (uint64_t)ctx->n_cu * std::max({ctx->blocks_per_cu, ctx->shade_blocks_per_cu, 8}) * (BLOCK / 64);
-    const uint64_t max_chunks = n_slots / (QUEUE_CHUNK - 63u) + max_waves + 8u;
+    uint64_t max_chunks, max_ray_chunks;
+    queue_capacity(ctx, n_slots, max_chunks, max_ray_chunks);
     ps.max_chunks = (uint32_t)max_chunks;
+    ps.max_ray_chunks = (uint32_t)max_ray_chunks;
+    ps.queue_overflow = &ctx->stats->queue_overflow;
     ps.n_queues = ctx->n_queues;
     for (int k = 0; k < 2; k++)
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_queue[k], max_chunks * QUEUE_CHUNK))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_queue[k], max_ray_chunks * QUEUE_CHUNK))) return rc;
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
@@ -971,7 +999,7 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
     ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
     ps.nee = ctx->nee ? 1u : 0u;
     if (ctx->nee) {
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_queue, max_chunks * QUEUE_CHUNK))) return rc;
+        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_queue, max_ray_chunks * QUEUE_CHUNK))) return rc;
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_c, n_slots))) return rc;
     }
     // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
@@ -1186,12 +1214,14 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
     if ((rc = dev_alloc(ctx, r.allocs, &ps.hit, total))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.hit2, total))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.contrib, total))) return rc;
-    const uint64_t max_waves = (uint64_t)ctx->n_cu * std::max({ctx->blocks_per_cu, ctx->shade_blocks_per_cu, 8}) * (BLOCK / 64);
-    const uint64_t max_chunks = total / (QUEUE_CHUNK - 63u) + max_waves + 8u;
+    uint64_t max_chunks, max_ray_chunks;
+    queue_capacity(ctx, total, max_chunks, max_ray_chunks);
     ps.max_chunks = (uint32_t)max_chunks;
+    ps.max_ray_chunks = (uint32_t)max_ray_chunks;
+    ps.queue_overflow = &ctx->stats->queue_overflow;
     ps.n_queues = ctx->n_queues;
     for (int k = 0; k < 2; k++)
-        if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_queue[k], max_chunks * QUEUE_CHUNK))) return rc;
+        if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_queue[k], max_ray_chunks * QUEUE_CHUNK))) return rc;
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, r.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
@@ -1200,7 +1230,7 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
     ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
     ps.nee = ctx->nee ? 1u : 0u;
     if (ctx->nee) {
-        if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_queue, max_chunks * QUEUE_CHUNK))) return rc;
+        if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_queue, max_ray_chunks * QUEUE_CHUNK))) return rc;
         if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_c, total))) return rc;
     }
     HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), pp.stream));
@@ -1219,7 +1249,9 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
 // Bytes ensure_roll allocates per pipe, near enough.
 static uint64_t roll_bytes(const pt_context *ctx, uint64_t n_regions, uint64_t cap) {
     const uint64_t total = n_regions * cap;
-    return total * (ctx->nee ? 100u : 84u) + (total + total / 3u) * 4u * (2u + ctx->n_queues + (ctx->nee ? 1u : 0u));
+    uint64_t max_chunks, max_ray_chunks;
+    queue_capacity(ctx, total, max_chunks, max_ray_chunks);
+    return total * (ctx->nee ? 100u : 84u) + (max_ray_chunks * (ctx->nee ? 3u : 2u) + max_chunks * ctx->n_queues) * QUEUE_CHUNK * 4u;
 }
 
 static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
@@ -1592,7 +1624,8 @@ int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_
     ps.ctl = (uint32_t *)(base + STATIC_OFF_CTL);
     ps.overflow = (uint2 *)(base + STATIC_OFF_OVERFLOW);
     ps.overflow_stride = STATIC_BLOCKS * BLOCK;
-    ps.max_chunks = (uint32_t)(STATIC_QUEUE_ENTRIES / QUEUE_CHUNK);
+    ps.max_chunks = ps.max_ray_chunks = (uint32_t)(STATIC_QUEUE_ENTRIES / QUEUE_CHUNK);
+    ps.queue_overflow = &ctx->stats->queue_overflow;
     ps.n_slots = (uint32_t)n;
     ps.refill_below = ctx->refill_below;
     ps.leaf_batch = ctx->leaf_batch;
@@ -1686,16 +1719,27 @@ int pt_read_accum(pt_context *ctx, float *rgb_sum, uint32_t *n_samples) {
     return PT_OK;
 }
 
+float *ptc_accum(pt_context *ctx) { return ctx->have_camera ? ctx->accum : nullptr; }
+uint64_t ptc_npix(const pt_context *ctx) { return ctx->have_camera ? (uint64_t)ctx->cam.width * ctx->cam.height : 0; }
+uint32_t ptc_n_samples(const pt_context *ctx) { return ctx->n_samples; }
+hipStream_t ptc_stream(pt_context *ctx) { return ctx->stream; }
+int ptc_device(const pt_context *ctx) { return ctx->device; }
+int ptc_tonemap(pt_context *ctx, const float *accum_device, uint32_t n_samples, uint8_t *rgb_host) {
+    if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t npix = ctx->cam.width * ctx->cam.height;
+    hipLaunchKernelGGL(k_tonemap, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, accum_device, ctx->rgb8, npix, (float)n_samples);
+    HIP_TRY(ctx, hipMemcpyAsync(rgb_host, ctx->rgb8, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
 int pt_read_rgb8(pt_context *ctx, uint8_t *rgb) {
     if (!ctx || !rgb) return fail(ctx, PT_ERR_INVALID, "NULL argument");
     if (!ctx->have_camera) return fail(ctx, PT_ERR_STATE, "no camera set");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const uint32_t npix = ctx->cam.width * ctx->cam.height;
     if (int rc = sync_all(ctx)) return rc;
-    hipLaunchKernelGGL(k_tonemap, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->accum, ctx->rgb8, npix, (float)ctx->n_samples);
-    HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->rgb8, (size_t)npix * 3, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return PT_OK;
+    return ptc_tonemap(ctx, ctx->accum, ctx->n_samples, rgb);
 }
 
 int pt_read_triangle_order(pt_context *ctx, uint32_t *order, uint32_t n) {

@@ -536,10 +536,30 @@ TreeNode *grow(BuildCtx &c, Arena &arena, size_t start, size_t end, uint32_t dep
     }
     constexpr size_t kOwnThread = 1u << 14;  // smaller subtrees are not worth a thread
     if (mid - start >= kOwnThread && end - mid >= kOwnThread && c.spare_threads.fetch_sub(1) > 0) {
+        // Nothing may leave this block by unwinding: a joinable std::thread that is destroyed, or an exception
+        // that escapes a thread's function, ends the process.  A failure in either half marks the build failed.
         TreeNode *left = nullptr;
-        std::thread t([&] { left = grow(c, c.new_arena(), start, mid, depth + 1); });
-        node->right = grow(c, arena, mid, end, depth + 1);
-        t.join();
+        std::thread t;
+        try {
+            t = std::thread([&] {
+                try {
+                    left = grow(c, c.new_arena(), start, mid, depth + 1);
+                } catch (...) {
+                    c.failed = true;
+                    left = nullptr;
+                }
+            });
+        } catch (...) {  // no thread to be had: this one does both halves
+        }
+        const bool threaded = t.joinable();
+        try {
+            node->right = grow(c, arena, mid, end, depth + 1);
+            if (!threaded) left = grow(c, arena, start, mid, depth + 1);
+        } catch (...) {
+            c.failed = true;
+            node->right = nullptr;
+        }
+        if (threaded) t.join();
         c.spare_threads.fetch_add(1);
         node->left = left;
     } else {

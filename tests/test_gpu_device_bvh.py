@@ -109,6 +109,21 @@ def test_small_buffers_and_duplicate_centres(n):
         assert np.array_equal(_original_tri_ids(host, rh, a), _original_tri_ids(dev, rd, b))
 
 
+def _all_tris(h):
+    from pathtracer_amd.core import pt_buffer_desc
+    return pt_buffer_desc(0, h.desc.n_tris, 0, 0)
+
+
+def _tri_first(h, hits):
+    """First scene-wide triangle index of the buffer each hit lies in (world set or the instance's child set)."""
+    first = np.full(hits.shape[0], h.set_desc(0).tris.prim_first, np.int64)
+    insts = h.set_desc(0).instances
+    for k in range(insts.prim_count):
+        child = h.desc.instances[insts.prim_first + k].child_set
+        first[hits["inst_id"] == k] = h.set_desc(child).tris.prim_first
+    return first
+
+
 def test_triangle_buffers_inside_instances_and_in_the_light_list():
     """Every triangle buffer above the threshold gets a device tree, the children of instances included; the light
     list is never traversed, so its triangles keep their order (LightBuffer::sample picks them by index)."""
@@ -134,6 +149,20 @@ def test_triangle_buffers_inside_instances_and_in_the_light_list():
     assert np.array_equal(a["t"].view(np.uint32), tuv[:, 0].view(np.uint32))
     assert np.array_equal(b["t"].view(np.uint32), a["t"].view(np.uint32))
     assert np.array_equal(a["prim_type"], b["prim_type"]) and np.array_equal(a["inst_id"], b["inst_id"])
+    # pt_read_triangle_order is a permutation of the uploaded triangles, also for the buffers of instanced sets (whose
+    # slices do not start at 0), and maps every hit back to the uploaded triangle the host-built tree names
+    order = rd.triangle_order()
+    assert np.array_equal(np.sort(order), np.arange(dev.desc.n_tris, dtype=np.uint32))
+    assert np.array_equal(rh.triangle_order(), np.arange(host.desc.n_tris, dtype=np.uint32))
+    tri = a["prim_type"] == 0
+    assert (tri & (a["inst_id"] >= 0)).sum() > 100 and (tri & (a["inst_id"] < 0)).sum() > 100
+    first_h, first_d = _tri_first(host, a), _tri_first(dev, b)
+    up_h = (first_h + a["prim_id"])[tri]                       # host build: positions are the uploaded ones
+    up_d = order[(first_d + b["prim_id"])[tri]]
+    th = host.triangles(_all_tris(host))[up_h]
+    td = dev.triangles(_all_tris(dev))[up_d]
+    same_tri = np.all(th == td, axis=1)
+    assert same_tri.mean() > 0.999, "hits inside device-built trees must map back to the triangles the host-built trees hit (exact ties aside)"
     # light sampling sees the same lights in the same order: same pdf for every ray, same image up to ties
     assert np.array_equal(rh.light_pdf(rays).view(np.uint32), rd.light_pdf(rays).view(np.uint32))
     for r in (rh, rd):
