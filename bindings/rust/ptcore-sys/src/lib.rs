@@ -217,9 +217,44 @@ pub struct pt_stats {
     pub bad_refs: u64,
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct pt_material_probe_in {
+    pub w_out: [f32; 3],
+    pub u: f32,
+    pub v: f32,
+    pub p: [f32; 3],
+    pub front_face: u32,
+    pub pixel: u32,
+    pub stratum: u32,
+    pub w_in: [f32; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct pt_material_probe_out {
+    pub w_in: [f32; 3],
+    pub draws: u32,
+    pub bsdf: [f32; 3],
+    pub pdf: f32,
+    pub bsdf_at: [f32; 3],
+    pub pdf_at: f32,
+    pub emitted: [f32; 3],
+    pub reserved: u32,
+}
+
+/// Largest `n` of `pt_trace_first_hit_static`.
+pub const PT_STATIC_TRACE_MAX_RAYS: u32 = 262144;
+
 /// Opaque: one context per GPU, not re-entrant.
 #[repr(C)]
 pub struct pt_context {
+    _private: [u8; 0],
+}
+
+/// Opaque: several GPUs of one node behind one handle, not re-entrant.
+#[repr(C)]
+pub struct pt_group {
     _private: [u8; 0],
 }
 
@@ -235,7 +270,9 @@ extern "C" {
     pub fn pt_render_samples(ctx: *mut pt_context, stratum_begin: u32, stratum_end: u32, seed: u64, out: *mut f32) -> i32;
     pub fn pt_generate_rays(ctx: *mut pt_context, stratum: u32, seed: u64, rays: *mut f32) -> i32;
     pub fn pt_trace_first_hit(ctx: *mut pt_context, rays: *const f32, n: u64, out: *mut pt_hit) -> i32;
+    pub fn pt_trace_first_hit_static(ctx: *mut pt_context, rays_device: *const f32, n: u64, out_device: *mut pt_hit) -> i32;
     pub fn pt_light_pdf(ctx: *mut pt_context, rays: *const f32, n: u64, tris_by_solid_angle: i32, out: *mut f32) -> i32;
+    pub fn pt_material_probe(ctx: *mut pt_context, material: i32, seed: u64, r#in: *const pt_material_probe_in, n: u64, out: *mut pt_material_probe_out) -> i32;
     pub fn pt_read_accum(ctx: *mut pt_context, rgb_sum: *mut f32, n_samples: *mut u32) -> i32;
     pub fn pt_read_rgb8(ctx: *mut pt_context, rgb: *mut u8) -> i32;
     pub fn pt_reset_accum(ctx: *mut pt_context) -> i32;
@@ -244,4 +281,20 @@ extern "C" {
     pub fn pt_set_accum_from_device(ctx: *mut pt_context, src_device: *const std::ffi::c_void, n_samples: u32) -> i32;
     pub fn pt_stats_get(ctx: *mut pt_context, out: *mut pt_stats) -> i32;
     pub fn pt_stats_reset(ctx: *mut pt_context) -> i32;
+    pub fn pt_group_create(devices: *const i32, n: i32, out: *mut *mut pt_group) -> i32;
+    pub fn pt_group_destroy(g: *mut pt_group);
+    pub fn pt_group_last_error(g: *const pt_group) -> *const c_char;
+    pub fn pt_group_size(g: *const pt_group) -> i32;
+    pub fn pt_group_member(g: *mut pt_group, i: i32) -> *mut pt_context;
+    pub fn pt_group_split(stratum_begin: u32, stratum_end: u32, n: i32, i: i32, begin_i: *mut u32, end_i: *mut u32);
+    pub fn pt_group_set_option(g: *mut pt_group, key: i32, value: f64) -> i32;
+    pub fn pt_group_upload_scene(g: *mut pt_group, scene: *const pt_scene_desc) -> i32;
+    pub fn pt_group_set_camera(g: *mut pt_group, camera: *const pt_camera_desc) -> i32;
+    pub fn pt_group_render(g: *mut pt_group, stratum_begin: u32, stratum_end: u32, seed: u64) -> i32;
+    pub fn pt_group_sync(g: *mut pt_group) -> i32;
+    pub fn pt_group_read_accum(g: *mut pt_group, rgb_sum: *mut f32, n_samples: *mut u32) -> i32;
+    pub fn pt_group_read_rgb8(g: *mut pt_group, rgb: *mut u8) -> i32;
+    pub fn pt_group_reset_accum(g: *mut pt_group) -> i32;
+    pub fn pt_group_stats_get(g: *mut pt_group, out: *mut pt_stats) -> i32;
+    pub fn pt_group_stats_reset(g: *mut pt_group) -> i32;
 }

@@ -191,31 +191,32 @@ impl FlatScene {
     }
 }
 
-/// A context that is destroyed when dropped; errors carry the library's text.
-pub struct Device(*mut pt_context);
+/// The GPUs a render runs on (`pt_group`: one context per device, strata split between them, one RCCL
+/// reduce of the accumulators when the image is read); destroyed when dropped; errors carry the library's text.
+pub struct Devices(*mut pt_group);
 
-impl Device {
-    pub fn new(device: i32) -> Result<Device, String> {
-        let mut ctx = std::ptr::null_mut();
-        let rc = unsafe { pt_create(device, &mut ctx) };
+impl Devices {
+    pub fn new(devices: &[i32]) -> Result<Devices, String> {
+        let mut g = std::ptr::null_mut();
+        let rc = unsafe { pt_group_create(devices.as_ptr(), devices.len() as i32, &mut g) };
         if rc != PT_OK {
             return Err(last_error(std::ptr::null()));
         }
-        Ok(Device(ctx))
+        Ok(Devices(g))
     }
     fn check(&self, rc: i32) -> Result<(), String> {
         if rc == PT_OK { Ok(()) } else { Err(last_error(self.0)) }
     }
 }
 
-impl Drop for Device {
+impl Drop for Devices {
     fn drop(&mut self) {
-        unsafe { pt_destroy(self.0) }
+        unsafe { pt_group_destroy(self.0) }
     }
 }
 
-fn last_error(ctx: *const pt_context) -> String {
-    unsafe { CStr::from_ptr(pt_last_error(ctx)) }.to_string_lossy().into_owned()
+fn last_error(g: *const pt_group) -> String {
+    unsafe { CStr::from_ptr(pt_group_last_error(g)) }.to_string_lossy().into_owned()
 }
 
 impl Camera {
@@ -233,18 +234,20 @@ impl Camera {
     /// `Camera::render` (src/camera.rs:162-236) on the device: same arguments, same image.  The passes of
     /// the stratum loop (:176-198) are handed over a few hundred at a time and the shared image is refreshed
     /// in between (the reference refreshes it after every pass, :221-226).
-    pub fn render_hip(&self, objects: &PrimitiveBuffer, lights: &LightBuffer, buffer: Arc<Mutex<RgbImage>>, seed: u64) -> Result<(), String> {
+    /// `devices`: the GPUs of this node to use, e.g. `&[0]` or `&[0, 1, 2, 3, 4, 5, 6, 7]`.
+    pub fn render_hip(&self, objects: &PrimitiveBuffer, lights: &LightBuffer, buffer: Arc<Mutex<RgbImage>>, devices: &[i32], seed: u64) -> Result<(), String> {
         let flat = FlatScene::describe(objects, lights);
-        let dev = Device::new(0)?;
-        dev.check(unsafe { pt_upload_scene(dev.0, &flat.desc()) })?;
-        dev.check(unsafe { pt_set_camera(dev.0, &self.describe()) })?;
+        let dev = Devices::new(devices)?;
+        dev.check(unsafe { pt_group_upload_scene(dev.0, &flat.desc()) })?;
+        dev.check(unsafe { pt_group_set_camera(dev.0, &self.describe()) })?;
         let total = self.sqrt_spp * self.sqrt_spp;
+        let per_refresh = 256 * devices.len() as u32;
         let mut begin = 0;
         while begin < total {
-            let end = (begin + 256).min(total);
-            dev.check(unsafe { pt_render(dev.0, begin, end, seed) })?;
+            let end = (begin + per_refresh).min(total);
+            dev.check(unsafe { pt_group_render(dev.0, begin, end, seed) })?;
             let mut img = buffer.lock().unwrap();
-            dev.check(unsafe { pt_read_rgb8(dev.0, img.as_mut_ptr()) })?;
+            dev.check(unsafe { pt_group_read_rgb8(dev.0, img.as_mut_ptr()) })?;
             begin = end;
         }
         Ok(())

@@ -66,8 +66,8 @@ def c_constants(text):
 
 def c_functions(text):
     out = {}
-    for m in re.finditer(r"^(const char \*|int |void )(pt_\w+)\(([^)]*)\);", text, flags=re.M):
-        ret = {"int ": "i32", "void ": None, "const char *": "*const c_char"}[m.group(1)]
+    for m in re.finditer(r"^(const char \*|pt_context \*|int |void )(pt_\w+)\(([^)]*)\);", text, flags=re.M):
+        ret = {"int ": "i32", "void ": None, "const char *": "*const c_char", "pt_context *": "*mut pt_context"}[m.group(1)]
         params = []
         for p in m.group(3).split(","):
             p = " ".join(p.split())
@@ -90,7 +90,7 @@ def rust_items(text):
     consts = {m.group(1): int(m.group(2).replace("_", ""), 0) for m in re.finditer(r"pub const (\w+): [iu]32 = (\w+);", text)}
     funcs = {}
     for m in re.finditer(r"pub fn (pt_\w+)\(([^)]*)\)( -> ([^;]+))?;", text):
-        params = [(p.split(":")[0].strip(), p.split(":", 1)[1].strip()) for p in m.group(2).split(", ")]
+        params = [(p.split(":")[0].replace("r#", "").strip(), p.split(":", 1)[1].strip()) for p in m.group(2).split(", ")]
         funcs[m.group(1)] = (params, m.group(4).strip() if m.group(4) else None)
     return structs, consts, funcs
 
@@ -103,7 +103,7 @@ def test_structs_field_for_field():
     want = c_structs(_headers())
     got, _, _ = rust_items(open(RS).read())
     used = ["pt_node", "pt_buffer_desc", "pt_primset_desc", "pt_instance_desc", "pt_material_desc", "pts_texture", "pts_image", "pts_medium",
-            "pt_scene_desc", "pt_camera_desc", "pt_hit", "pt_stats"]
+            "pt_scene_desc", "pt_camera_desc", "pt_hit", "pt_stats", "pt_material_probe_in", "pt_material_probe_out"]
     for name in used:
         assert name in got, name
         assert got[name] == want[name], (name, got[name], want[name])
