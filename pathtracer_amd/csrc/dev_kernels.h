@@ -29,13 +29,18 @@ struct BatchParams {
     float bsdf_prob;
     f3 background;
 };
-// Paths of a batch are numbered pixel-major: slot = pixel * n_strata + (stratum - stratum_first).
-// The 64 lanes of a wave then hold the strata of a few neighbouring pixels — almost the same
-// ray — and a contiguous range of slots is a band of the image with all its strata, which is
-// what the per-XCD split of the queues below relies on for L2 locality.
-__device__ __forceinline__ void slot_to_sample(const BatchParams &bp, uint32_t slot, uint32_t &pixel, uint32_t &stratum) {
-    pixel = slot / bp.n_strata;
-    stratum = bp.stratum_first + (slot - pixel * bp.n_strata);
+// Paths of a batch are numbered pixel-major: slot = first slot of the batch + pixel * n_strata + (stratum -
+// stratum_first).  The 64 lanes of a wave then hold the strata of a few neighbouring pixels — almost the same
+// ray — and a contiguous range of slots is a band of the image with all its strata.  The slot arrays are cut
+// into regions of ps.region_cap slots, one batch per region (a single region where batches do not share
+// launches), and a path's batch is found from its slot.
+__device__ __forceinline__ void path_sample(const PathState &ps, uint32_t slot, uint64_t &seed_mixed, uint32_t &pixel, uint32_t &stratum) {
+    const uint32_t region = slot / ps.region_cap;
+    const RegionParams rp = ps.regions[region];
+    const uint32_t local = slot - region * ps.region_cap;
+    pixel = local / rp.n_strata;
+    stratum = rp.stratum_first + (local - pixel * rp.n_strata);
+    seed_mixed = rp.seed_mixed;
 }
 
 // Consumer side of a chunked queue with a fixed share per wave: wave w takes the 64-entry
@@ -91,44 +96,47 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint3
     d = pixel_center - ray_center;
 }
 
-// ROLL: the batch goes to the region starting at slot `base`, whose parameters are recorded for
-// the kernels that meet its paths later, and no queue is written: the closest-hit kernel takes
-// the new paths by their slot numbers.
-template <bool ROLL>
-__global__ __launch_bounds__(BLOCK) void k_raygen(DevCamera cam, PathState ps, BatchParams bp, uint32_t base, DevStats *stats) {
-    const uint32_t n = bp.n_slots;
-    for (uint32_t local = blockIdx.x * BLOCK + threadIdx.x; local < n; local += gridDim.x * BLOCK) {
-        uint32_t pixel, stratum;
-        slot_to_sample(bp, local, pixel, stratum);
-        Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, 0u);
-        f3 o, d;
-        camera_ray(cam, rng, pixel, stratum, o, d);
-        const uint32_t slot = base + local;
-        ps.ray_o[slot] = make_float4(o.x, o.y, o.z, __uint_as_float(rng.counter));
-        ps.ray_d[slot] = make_float4(d.x, d.y, d.z, __uint_as_float(cam.max_depth));
-        ps.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, ps.moving ? path_time(rng.key) : 0.0f);
-        ps.contrib[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (!ROLL) ps.ray_queue[0][slot] = slot;
-    }
-    if (blockIdx.x == 0) {
-        if (!ROLL) {
-            const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
-            for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
-            if (threadIdx.x == 0) ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
-        } else if (threadIdx.x == 0) {
-            RegionParams rp{};
-            rp.seed_mixed = bp.seed_mixed;
-            rp.stratum_first = bp.stratum_first;
-            rp.n_strata = bp.n_strata;
-            ps.regions[base / ps.region_cap] = rp;
-        }
-        if (threadIdx.x == 0) {
-            atomicAdd(&stats->paths_total, (unsigned long long)n);
-            atomicAdd(&stats->rays_total, (unsigned long long)n);
-        }
+// The paths that start with a launch ("fresh" paths: the `n_new` paths in slots new_base ..) are on their camera
+// ray, which is never stored: whoever needs it computes it again from the path's pixel and stratum, together
+// with what else a path carries at that point (draws consumed so far, full depth, throughput 1).
+struct FreshPaths {
+    uint32_t new_base, n_new;
+    __device__ __forceinline__ bool holds(uint32_t slot) const { return slot - new_base < n_new; }
+};
+__device__ __forceinline__ void fresh_path(const DevCamera &cam, const PathState &ps, uint32_t slot, f3 &o, f3 &d, uint32_t &draws, float &time) {
+    uint64_t seed_mixed;
+    uint32_t pixel, stratum;
+    path_sample(ps, slot, seed_mixed, pixel, stratum);
+    Rng rng;
+    rng.init(seed_mixed, pixel, stratum, 0u);
+    camera_ray(cam, rng, pixel, stratum, o, d);
+    draws = rng.counter;
+    time = ps.moving ? path_time(rng.key) : 0.0f;
+}
+// Origin and direction of the ray a path is on.
+__device__ __forceinline__ void path_ray(const DevCamera &cam, const PathState &ps, uint32_t slot, bool fresh, f3 &o, f3 &d) {
+    if (fresh) {
+        uint32_t draws;
+        float time;
+        fresh_path(cam, ps, slot, o, d, draws, time);
+    } else {
+        const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+        o = mk3(ro.x, ro.y, ro.z);
+        d = mk3(rd.x, rd.y, rd.z);
     }
 }
+// Entry i of a launch's work: the entries of the ray queue first (`queued` of them, padding included), then the
+// fresh paths.  False for padding and past the end.
+__device__ __forceinline__ bool work_entry(const uint32_t *queue, uint32_t queued, const FreshPaths &fp, uint32_t i, uint32_t &slot, bool &fresh) {
+    fresh = i >= queued;
+    if (!fresh) {
+        slot = queue[i];
+        return slot != QUEUE_EMPTY;
+    }
+    slot = fp.new_base + (i - queued);
+    return i - queued < fp.n_new;
+}
+__global__ void k_set_region(RegionParams *regions, uint32_t region, RegionParams rp) { regions[region] = rp; }
 
 // Rays only (pt_generate_rays).
 __global__ __launch_bounds__(BLOCK) void k_raygen_only(DevCamera cam, BatchParams bp, float *rays) {
@@ -151,8 +159,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // material finish here (src/camera.rs:371, :277-283); the others are appended to the queue
 // of their material type.  Every lane of the wave must call this (inactive lanes with
 // active == false), after shade_push_init() and before shade_push_close().
+// fresh: the path is on its camera ray (throughput 1, nothing stored for it yet).
 __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, uint32_t parity, f3 background, bool active,
-                                         uint32_t slot, uint32_t code, uint32_t prim) {
+                                         uint32_t slot, uint32_t code, uint32_t prim, bool fresh) {
     uint32_t qslot = 0xFFu;
     if (active) {
         int32_t mat = -1;
@@ -164,12 +173,12 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
         // may still scatter on its way out, and shade_vertex<PTD_MAT_MEDIUM> decides (medium_queue is 0xFF otherwise)
         qslot = mat >= 0 ? sc.mat_queue[mat] : sc.medium_queue;
         if (qslot == 0xFFu) {
+            const float4 b = fresh ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ps.beta[slot];
             if (!ps.nee) {
-                const float4 b = ps.beta[slot];
                 const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
                 ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
             } else if (code == PTD_HIT_MISS) {  // contrib already holds the light samples of the earlier vertices
-                const float4 b = ps.beta[slot], c = ps.contrib[slot];
+                const float4 c = ps.contrib[slot];
                 ps.contrib[slot] = make_float4(c.x + b.x * background.x, c.y + b.y * background.y, c.z + b.z * background.z, 0.0f);
             }
         }
@@ -195,12 +204,16 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
 
 // What every closest-hit kernel does first: clear the control words the shade kernels of
 // this bounce will fill, and count the launch.
-__device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bounce, uint32_t n_chunks, DevStats *stats) {
+__device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bounce, uint32_t n_chunks, uint32_t n_new, DevStats *stats) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t parity = bounce & 1u;
         ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
         ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        if (n_chunks) atomicAdd(&stats->extend_nonempty, 1ull);
+        if (n_chunks + n_new) atomicAdd(&stats->extend_nonempty, 1ull);
+        if (n_new) {  // the paths that start with this launch, and their camera rays
+            atomicAdd(&stats->paths_total, (unsigned long long)n_new);
+            atomicAdd(&stats->rays_total, (unsigned long long)n_new);
+        }
     }
 }
 
@@ -216,33 +229,35 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 }
 
 // Closest hit among the world's triangles, spheres and quads for every ray of the current
-// queue (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
+// queue and every fresh path (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
 template <bool COUNT, bool CLASSIFY>
-__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
-    extend_prologue(ps, bounce, n_chunks, stats);
+    extend_prologue(ps, bounce, n_chunks, fp.n_new, stats);
     if (CLASSIFY) shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        const bool active = slot != QUEUE_EMPTY;
+    const uint32_t queued = n_chunks * QUEUE_CHUNK, n_pieces = queued / 64u + (fp.n_new + 63u) / 64u;
+    for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
+        uint32_t slot;
+        bool fresh;
+        const bool active = work_entry(queue, queued, fp, piece * 64u + lane_id(), slot, fresh);
         HitState h;
         h.code = PTD_HIT_MISS;
         h.prim = 0;
         if (active) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            f3 o, d;
+            path_ray(cam, ps, slot, fresh, o, d);
+            TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
             hit_world_prims(sc, r, h, st, tc);
             ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
             ps.hit2[slot] = h.code;
         }
-        if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim);
+        if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim, fresh);
     }
     if (CLASSIFY) shade_push_close(ps);
     flush_counters(COUNT, tc, stats);
@@ -251,23 +266,23 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, PathState ps, uin
 // The whole of PrimitiveBuffer::hit with rays drawn by the waves as their lanes fall idle
 // (dev_walk.h); this is the form used for rendering whenever the scene's leaves fit the
 // 64-byte node layout.  INSTANCES: the world has an instance buffer.
-#ifdef PT_WALK_WAVES
-#define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
-#else
-#define WALK_OCCUPANCY
+// Five workgroups of four waves per CU is what the LDS stacks allow; the register budget follows from it
+// (at most 96 VGPRs per lane for five waves per SIMD).
+#ifndef PT_WALK_WAVES
+#define PT_WALK_WAVES 5
 #endif
-// The work is the current ray queue followed by the `n_new` paths in slots new_base.. that a
-// k_raygen<true> has just started (no queue entries exist for those).
+#define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
+// The work is the current ray queue followed by the fresh paths (no queue entries exist for those).
 // MOVING: the scene has moving spheres (pts_moving_sphere): a finished ray is tested against them, where
 // they are at its path's time, before it is classified.
 template <bool INSTANCES, bool MOVING>
-__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, PathState ps, uint32_t bounce, f3 background, uint32_t new_base,
-                                                                      uint32_t n_new, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp,
+                                                                      DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
-    extend_prologue(ps, bounce, n_chunks + n_new, stats);
+    extend_prologue(ps, bounce, n_chunks, fp.n_new, stats);
     const uint32_t queued = n_chunks * QUEUE_CHUNK;
-    const uint32_t n_pieces = queued / 64u + (n_new + 63u) / 64u;
+    const uint32_t n_pieces = queued / 64u + (fp.n_new + 63u) / 64u;
     if (n_pieces == 0u) return;
     shade_push_init();
     LaneStack st;
@@ -276,28 +291,28 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
     walk_world<INSTANCES>(
         sc, n_pieces, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            if (i < queued) {
-                slot = queue[i];
-                if (slot == QUEUE_EMPTY) return false;
-            } else {
-                if (i - queued >= n_new) return false;
-                slot = new_base + (i - queued);
-            }
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            bool fresh;
+            if (!work_entry(queue, queued, fp, i, slot, fresh)) return false;
+            f3 o, d;
+            path_ray(cam, ps, slot, fresh, o, d);
+            r = make_trav_ray(o, d, 0.001f, INFINITY);
             return true;
         },
-        [&](uint32_t slot, f3 &o, f3 &d) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            o = mk3(ro.x, ro.y, ro.z);
-            d = mk3(rd.x, rd.y, rd.z);
-        },
+        [&](uint32_t slot, f3 &o, f3 &d) { path_ray(cam, ps, slot, fp.holds(slot), o, d); },
         [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
+            const bool fresh = fp.holds(slot);
             if constexpr (MOVING) {
                 TravRay r2 = r;
                 HitState h2 = h;
                 if (done) {
-                    const float time = ps.beta[slot].w;
+                    float time;
+                    if (fresh) {
+                        f3 o, d;
+                        uint32_t draws;
+                        fresh_path(cam, ps, slot, o, d, draws, time);
+                    } else {
+                        time = ps.beta[slot].w;
+                    }
                     for (uint32_t k = 0; k < sc.n_moving; k++) {
                         const uint32_t g = sc.n_static_spheres + k;
                         const float4 sp = sc.spheres[g], dl = sc.moving_delta[k];
@@ -307,13 +322,13 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
                     ps.hit[slot] = make_float4(r2.t_max, h2.u, h2.v, __uint_as_float(h2.prim));
                     ps.hit2[slot] = h2.code;
                 }
-                classify(sc, ps, parity, background, done, slot, h2.code, h2.prim);
+                classify(sc, ps, parity, background, done, slot, h2.code, h2.prim, fresh);
             } else {
                 if (done) {
                     ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
                     ps.hit2[slot] = h.code;
                 }
-                classify(sc, ps, parity, background, done, slot, h.code, h.prim);
+                classify(sc, ps, parity, background, done, slot, h.code, h.prim, fresh);
             }
         });
     shade_push_close(ps);
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
 // continuing from the hit and t_max the first kernel left; then classification.
 template <bool COUNT>
-__global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps, uint32_t bounce, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     shade_push_init();
@@ -330,20 +345,23 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const uint32_t *queue = ps.ray_queue[parity];
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        const bool active = slot != QUEUE_EMPTY;
+    const uint32_t queued = n_chunks * QUEUE_CHUNK, n_pieces = queued / 64u + (fp.n_new + 63u) / 64u;
+    for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
+        uint32_t slot;
+        bool fresh;
+        const bool active = work_entry(queue, queued, fp, piece * 64u + lane_id(), slot, fresh);
         HitState h;
         h.code = PTD_HIT_MISS;
         h.prim = 0;
         if (active) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot], h4 = ps.hit[slot];
+            f3 o, d;
+            path_ray(cam, ps, slot, fresh, o, d);
+            const float4 h4 = ps.hit[slot];
             h.u = h4.y;
             h.v = h4.z;
             h.prim = __float_as_uint(h4.w);
             h.code = ps.hit2[slot];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, h4.x);
+            TravRay r = make_trav_ray(o, d, 0.001f, h4.x);
             const uint32_t before = h.code;
             const float t_before = r.t_max;
             hit_world_insts(sc, r, h, st, tc);
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
                 ps.hit2[slot] = h.code;
             }
         }
-        classify(sc, ps, parity, background, active, slot, h.code, h.prim);
+        classify(sc, ps, parity, background, active, slot, h.code, h.prim, fresh);
     }
     shade_push_close(ps);
     flush_counters(COUNT, tc, stats);
@@ -360,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, PathState ps
 
 // The surface part of shade_vertex below.
 template <int MT, bool NEE>
-__device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow,
+__device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, bool &shadow,
                                               f3 ro, f3 rd, float4 h4, float4 b4, uint32_t code, f3 beta, uint32_t depth, uint32_t rng_counter) {
     const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code, NEE ? 0.0f : b4.w);
     const DevMaterial m = sc.mats[s.material];
@@ -379,10 +397,11 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
             ps.contrib[slot] = make_float4(beta.x * e.x, beta.y * e.y, beta.z * e.z, 0.0f);
         }
     } else {
+        uint64_t seed_mixed;
         uint32_t pixel, stratum;
-        slot_to_sample(bp, local, pixel, stratum);
+        path_sample(ps, slot, seed_mixed, pixel, stratum);
         Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, rng_counter);
+        rng.init(seed_mixed, pixel, stratum, rng_counter);
         const Onb surface = make_onb(s.normal);
         const f3 w_out = -normalize(to_local(surface, rd));
         f3 w_in_world;
@@ -488,20 +507,35 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
 // sp' / (sp' + lp'), and fully after the camera or a vertex without light sampling.  Radiance is
 // added to ps.contrib as it is found; paths that end without finding any add nothing.
 template <int MT, bool NEE, bool MEDIA = false>
-__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, uint32_t local, bool &shadow) {
-    const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot], h4 = ps.hit[slot], b4 = ps.beta[slot];
+__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const DevCamera &cam, const PathState &ps, const BatchParams &bp, uint32_t slot, bool fresh, bool &shadow) {
+    f3 ro, rd;
+    float4 b4;
+    uint32_t depth;        // the max_depth argument of this ray_color call, >= 1
+    uint32_t rng_counter;  // draws the path has consumed so far
+    if (fresh) {  // the camera ray is not stored anywhere: src/camera.rs:207-210 with the path's own generator again
+        float time;
+        fresh_path(cam, ps, slot, ro, rd, rng_counter, time);
+        depth = cam.max_depth;
+        b4 = make_float4(1.0f, 1.0f, 1.0f, time);
+    } else {
+        const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot];
+        ro = mk3(ro4.x, ro4.y, ro4.z);
+        rd = mk3(rd4.x, rd4.y, rd4.z);
+        rng_counter = __float_as_uint(ro4.w);
+        depth = __float_as_uint(rd4.w);
+        b4 = ps.beta[slot];
+    }
+    const float4 h4 = ps.hit[slot];
     const uint32_t code = ps.hit2[slot];
-    const f3 ro = mk3(ro4.x, ro4.y, ro4.z), rd = mk3(rd4.x, rd4.y, rd4.z);
     f3 beta = mk3(b4.x, b4.y, b4.z);
-    uint32_t depth = __float_as_uint(rd4.w);  // the max_depth argument of this ray_color call, >= 1
     shadow = false;
-    uint32_t rng_counter = __float_as_uint(ro4.w);
     if constexpr (MT == PTD_MAT_MEDIUM || MEDIA) {
         // participating media (not in the reference): the ray may scatter before it reaches what it hit
+        uint64_t seed_mixed;
         uint32_t pixel, stratum;
-        slot_to_sample(bp, local, pixel, stratum);
+        path_sample(ps, slot, seed_mixed, pixel, stratum);
         Rng rng;
-        rng.init(bp.seed_mixed, pixel, stratum, rng_counter);
+        rng.init(seed_mixed, pixel, stratum, rng_counter);
         const bool missed = MT == PTD_MAT_MEDIUM && code == PTD_HIT_MISS;
         float t_event;
         uint32_t which = 0u;
@@ -528,16 +562,16 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const PathState
         }
     }
     if constexpr (MT == PTD_MAT_MEDIUM) return false;
-    else return shade_surface<MT, NEE>(sc, ps, bp, slot, local, shadow, ro, rd, h4, b4, code, beta, depth, rng_counter);
+    else return shade_surface<MT, NEE>(sc, ps, bp, slot, shadow, ro, rd, h4, b4, code, beta, depth, rng_counter);
 }
 
 // shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
-// ROLL: the queue mixes batches, `bp` holds what they have in common and the rest comes from the
-// path's region.
+// The queue may mix batches (each at a different bounce): `bp` holds what they have in common (sampling
+// probability, background), the rest comes from the path's region; `fp` names the paths on their camera ray.
 // MODE: 0 = the reference's estimator, 1 = next-event estimation, 2 = the reference's estimator in a scene with
 // participating media.
-template <int MT, bool ROLL, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, DevStats *stats) {
+template <int MT, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, FreshPaths fp, DevStats *stats) {
     constexpr bool NEE = MODE == 1, MEDIA = MODE == 2;
     // a path ends at an emitter (src/camera.rs:288-290), unless a medium scatters it on its way there
     constexpr bool CONTINUES = MT != PTS_MAT_DIFFUSE_LIGHT || MEDIA;
@@ -553,19 +587,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
     for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
         const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
         bool alive = false, shadow = false;
-        if (slot != QUEUE_EMPTY) {
-            if constexpr (ROLL) {
-                const uint32_t region = slot / ps.region_cap;
-                const RegionParams rp = ps.regions[region];
-                BatchParams mine = bp;
-                mine.seed_mixed = rp.seed_mixed;
-                mine.stratum_first = rp.stratum_first;
-                mine.n_strata = rp.n_strata;
-                alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, mine, slot, slot - region * ps.region_cap, shadow);
-            } else {
-                alive = shade_vertex<MT, NEE, MEDIA>(sc, ps, bp, slot, slot, shadow);
-            }
-        }
+        if (slot != QUEUE_EMPTY) alive = shade_vertex<MT, NEE, MEDIA>(sc, cam, ps, bp, slot, fp.holds(slot), shadow);
         if constexpr (CONTINUES) {
             survivors += (uint32_t)__popcll(__ballot(alive));
             wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE], ps.max_ray_chunks, ps.queue_overflow);
@@ -580,7 +602,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
         if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
         if (survivors && lane_id() == 0u) {
             atomicAdd(&stats->rays_total, (unsigned long long)survivors);
-            if (!ROLL && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
+            if (ps.bounce_rays && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
         }
     }
 }
@@ -588,7 +610,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, PathState ps, Batc
 // Shadow rays of one step (next-event estimation): closest hit along each, and where that is an
 // emitter, its radiance times the factor the vertex left behind goes to the path.
 template <bool INSTANCES>
-__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the shading of the next step
@@ -634,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene s
 // launches then cost more in launch latency than the work they carry, and this also covers
 // however many bounces remain without the host having to know.  The functions are the ones the
 // per-bounce kernels call, so every path gets the same arithmetic.
-__global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, BatchParams bp, uint32_t bounce, f3 background, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, f3 background, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     LaneStack st;
@@ -668,16 +690,16 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, Batch
             ps.hit2[slot] = h.code;
             bool alive = false, shadow;
             switch (sc.mats[mat].type) {
-                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT, false>(sc, ps, bp, slot, slot, shadow); break;
-                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN, false>(sc, ps, bp, slot, slot, shadow); break;
+                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT, false>(sc, cam, ps, bp, slot, false, shadow); break;
+                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN, false>(sc, cam, ps, bp, slot, false, shadow); break;
                 default: break;
             }
             if (!alive) break;
@@ -687,20 +709,57 @@ __global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, PathState ps, Batch
     if (traced) atomicAdd(&stats->rays_total, (unsigned long long)traced);
 }
 
-// `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).
-__global__ __launch_bounds__(BLOCK) void k_accumulate(const float4 *contrib, float *accum, uint32_t npix, uint32_t n_strata) {
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
-        float r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2];
-        for (uint32_t k = 0; k < n_strata; k++) {
-            const float4 c = contrib[(size_t)p * n_strata + k];
-            if (c.x != c.x || c.y != c.y || c.z != c.z) continue;
-            r += c.x;
-            g += c.y;
-            b += c.z;
+// `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).  The
+// radiance slots are left at zero for the batch that uses them next: a path that ends without finding light
+// (Russian roulette, src/camera.rs:355-357) writes nothing.
+// Each workgroup takes BLOCK consecutive pixels at a time: their slots are one contiguous stretch, which the
+// workgroup copies to LDS with coalesced loads (and clears with coalesced stores); each thread then adds up its
+// own pixel's strata, in order, from LDS.
+constexpr uint32_t ACC_LDS_SLOTS = 2560;  // 40 KB
+__global__ __launch_bounds__(BLOCK) void k_accumulate(float4 *contrib, float *accum, uint32_t npix, uint32_t n_strata) {
+    __shared__ float4 tile[ACC_LDS_SLOTS];
+    const uint32_t per_pass = ACC_LDS_SLOTS / n_strata < (uint32_t)BLOCK ? ACC_LDS_SLOTS / n_strata : (uint32_t)BLOCK;  // pixels per pass
+    if (per_pass == 0u) {  // more strata per pixel than the tile holds: straight from memory
+        for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < npix; p += gridDim.x * BLOCK) {
+            float r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2];
+            for (uint32_t k = 0; k < n_strata; k++) {
+                const float4 c = contrib[(size_t)p * n_strata + k];
+                contrib[(size_t)p * n_strata + k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (c.x != c.x || c.y != c.y || c.z != c.z) continue;
+                r += c.x;
+                g += c.y;
+                b += c.z;
+            }
+            accum[3 * p] = r;
+            accum[3 * p + 1] = g;
+            accum[3 * p + 2] = b;
         }
-        accum[3 * p] = r;
-        accum[3 * p + 1] = g;
-        accum[3 * p + 2] = b;
+        return;
+    }
+    for (uint32_t first = blockIdx.x * per_pass; first < npix; first += gridDim.x * per_pass) {
+        const uint32_t n_pix = npix - first < per_pass ? npix - first : per_pass;
+        const uint32_t n_slots = n_pix * n_strata;
+        float4 *src = contrib + (size_t)first * n_strata;
+        for (uint32_t i = threadIdx.x; i < n_slots; i += BLOCK) {
+            tile[i] = src[i];
+            src[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+        if (threadIdx.x < n_pix) {
+            const uint32_t p = first + threadIdx.x;
+            float r = accum[3 * p], g = accum[3 * p + 1], b = accum[3 * p + 2];
+            for (uint32_t k = 0; k < n_strata; k++) {
+                const float4 c = tile[threadIdx.x * n_strata + k];
+                if (c.x != c.x || c.y != c.y || c.z != c.z) continue;
+                r += c.x;
+                g += c.y;
+                b += c.z;
+            }
+            accum[3 * p] = r;
+            accum[3 * p + 1] = g;
+            accum[3 * p + 2] = b;
+        }
+        __syncthreads();
     }
 }
 

@@ -996,6 +996,9 @@ static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots)
         if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
+    if ((rc = dev_alloc(ctx, pp.allocs, &ps.regions, (size_t)1))) return rc;
+    // radiance slots start at zero and are left at zero by whoever reads them (k_accumulate, pt_render_samples)
+    HIP_TRY(ctx, hipMemsetAsync(ps.contrib, 0, n_slots * sizeof(float4), pp.stream));
     ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
     ps.nee = ctx->nee ? 1u : 0u;
     if (ctx->nee) {
@@ -1024,17 +1027,17 @@ static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
 }
 
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
-// new_base, n_new: paths a k_raygen<true> has just started (only with the ray-drawing kernel).
-static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, uint32_t new_base = 0, uint32_t n_new = 0) {
+// fp: the paths that start with this step (on their camera rays; nothing is stored for them).
+static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, FreshPaths fp) {
     const dim3 g(grid), b(BLOCK);
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
-#define EXT(C, K) hipLaunchKernelGGL((k_extend<C, K>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats)
-#define EXI(C) hipLaunchKernelGGL((k_extend_inst<C>), g, b, 0, st, ctx->scene, ps, bounce, bg, ctx->stats)
+#define EXT(C, K) hipLaunchKernelGGL((k_extend<C, K>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
+#define EXI(C) hipLaunchKernelGGL((k_extend_inst<C>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
     if (ctx->counters) {
         if (insts) { EXT(true, false); EXI(true); } else EXT(true, true);
     } else if (ctx->use_wide()) {
-#define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ps, bounce, bg, new_base, n_new, ctx->stats)
+#define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
         if (ctx->scene.n_moving != 0) {
             if (insts) EXW(true, true); else EXW(false, true);
         } else {
@@ -1060,18 +1063,14 @@ struct ShadeLaunch {
     int grid;
     const BatchParams *bp;
     uint32_t bounce, q;
-    bool roll = false;
+    FreshPaths fp;
 };
 template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
-#define SHADE(R, N) hipLaunchKernelGGL((k_shade<MT, R, N>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, *l.ps, *l.bp, l.bounce, l.q, l.ctx->stats)
-    if (l.ps->nee) {
-        if (l.roll) SHADE(true, 1); else SHADE(false, 1);
-    } else if (l.ctx->scene.n_media != 0) {
-        if (l.roll) SHADE(true, 2); else SHADE(false, 2);
-    } else {
-        if (l.roll) SHADE(true, 0); else SHADE(false, 0);
-    }
+#define SHADE(N) hipLaunchKernelGGL((k_shade<MT, N>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, l.ctx->cam, *l.ps, *l.bp, l.bounce, l.q, l.fp, l.ctx->stats)
+    if (l.ps->nee) SHADE(1);
+    else if (l.ctx->scene.n_media != 0) SHADE(2);
+    else SHADE(0);
 #undef SHADE
 }
 static void launch_shade_type(int type, const ShadeLaunch &l) {
@@ -1144,13 +1143,18 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(pp.ps.bounce_rays, 0, BOUNCE_PROFILE_LEN * sizeof(uint32_t), st));
     pp.ps.n_slots = (uint32_t)n_slots;
+    pp.ps.region_cap = (uint32_t)n_slots;  // one region: the batch
     pp.ps.refill_below = ctx->refill_below;
     pp.ps.leaf_batch = ctx->leaf_batch;
     const PathState ps = pp.ps;
+    RegionParams rp{};
+    rp.seed_mixed = bp.seed_mixed;
+    rp.stratum_first = first;
+    rp.n_strata = k;
+    hipLaunchKernelGGL(k_set_region, dim3(1), dim3(1), 0, st, ps.regions, 0u, rp);
     size_t ev = 0;
     const bool prof = ctx->profile;
-    if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-    hipLaunchKernelGGL(k_raygen<false>, dim3(grid_for(ctx, n_slots)), dim3(BLOCK), 0, st, ctx->cam, ps, bp, 0u, ctx->stats);
+    if (prof) (void)hipEventRecord(get_event(pp, ev++), st);  // (the two events that used to bracket ray generation)
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     const int grid = grid_fixed(ctx, n_slots), grid_shade = grid_fixed(ctx, n_slots, ctx->shade_blocks_per_cu);
     const uint32_t depth = ctx->cam.max_depth;
@@ -1180,7 +1184,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
             g_sh = std::min(grid_shade, (want + 7) / 8 * 8);
         }
         if (b == tail_from) {
-            hipLaunchKernelGGL(k_tail, dim3(g_ext), dim3(BLOCK), 0, st, ctx->scene, ps, bp, b, ctx->cam.background, ctx->stats);
+            hipLaunchKernelGGL(k_tail, dim3(g_ext), dim3(BLOCK), 0, st, ctx->scene, ctx->cam, ps, bp, b, ctx->cam.background, ctx->stats);
             if (prof) {
                 (void)hipEventRecord(get_event(pp, ev++), st);
                 (void)hipEventRecord(get_event(pp, ev++), st);
@@ -1188,9 +1192,10 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
             bounces++;
             break;
         }
-        launch_extend(ctx, st, g_ext, ps, b);
+        const FreshPaths fp{0u, b == 0u ? (uint32_t)n_slots : 0u};  // every path of the batch starts with its first step
+        launch_extend(ctx, st, g_ext, ps, b, fp);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, q});
+        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, q, fp});
         if (ctx->nee) launch_shadow(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
@@ -1225,8 +1230,9 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, r.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, r.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
+    ps.bounce_rays = nullptr;  // rays per bounce are only recorded where a batch has its launches to itself
     if ((rc = dev_alloc(ctx, r.allocs, &ps.regions, (size_t)n_regions))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(ps.contrib, 0, total * sizeof(float4), pp.stream));  // see ensure_paths
     ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
     ps.nee = ctx->nee ? 1u : 0u;
     if (ctx->nee) {
@@ -1289,22 +1295,26 @@ static int roll_step(pt_context *ctx, const BatchParams *nb) {
     const uint32_t parity = (uint32_t)(r.tick & 1u);
     const bool prof = ctx->profile;
     if (prof) (void)hipEventRecord(r.prof[ring][0], st);
-    uint32_t n_new = 0;
+    FreshPaths fp{base, 0u};
     if (nb) {
-        n_new = nb->n_slots;
-        hipLaunchKernelGGL(k_raygen<true>, dim3(grid_for(ctx, n_new)), dim3(BLOCK), 0, st, ctx->cam, ps, *nb, base, ctx->stats);
+        fp.n_new = nb->n_slots;
+        RegionParams rp{};
+        rp.seed_mixed = nb->seed_mixed;
+        rp.stratum_first = nb->stratum_first;
+        rp.n_strata = nb->n_strata;
+        hipLaunchKernelGGL(k_set_region, dim3(1), dim3(1), 0, st, ps.regions, region, rp);
         r.due.push_back({r.tick + depth - 1u, region, nb->n_strata});
     }
     if (prof) (void)hipEventRecord(r.prof[ring][1], st);
     const uint64_t bound = (uint64_t)r.n_regions * r.cap;
-    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, base, n_new);
+    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp);
     if (prof) (void)hipEventRecord(r.prof[ring][2], st);
     BatchParams common{};
     common.npix = ctx->cam.width * ctx->cam.height;
     common.bsdf_prob = ctx->nee ? 1.0f : ctx->bsdf_prob;
     common.background = ctx->cam.background;
     const int grid_shade = grid_fixed(ctx, bound, ctx->shade_blocks_per_cu);
-    for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, true});
+    for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, fp});
     if (ctx->nee) launch_shadow(ctx, st, grid_fixed(ctx, bound), ps, parity);
     if (prof) {
         (void)hipEventRecord(r.prof[ring][3], st);
@@ -1487,6 +1497,7 @@ int pt_render_samples(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_
         const size_t n = (size_t)npix * k;
         host.resize(n);
         hipError_t e = hipMemcpyAsync(host.data(), pp.ps.contrib, n * sizeof(float4), hipMemcpyDeviceToHost, pp.stream);
+        if (e == hipSuccess) e = hipMemsetAsync(pp.ps.contrib, 0, n * sizeof(float4), pp.stream);  // as k_accumulate leaves them
         if (e == hipSuccess) e = hipStreamSynchronize(pp.stream);
         if (e != hipSuccess) {
             rc = fail(ctx, PT_ERR_HIP, "pt_render_samples: %s", hipGetErrorString(e));
