@@ -20,6 +20,7 @@ pub const PT_PRIM_TRI: i32 = 0;
 pub const PT_PRIM_SPHERE: i32 = 1;
 pub const PT_PRIM_QUAD: i32 = 2;
 pub const PT_PRIM_INSTANCE: i32 = 3;
+pub const PT_PRIM_MOVING_SPHERE: i32 = 4;
 
 pub const PT_NODE_LEAF: u32 = 0x8000_0000;
 
@@ -270,6 +271,7 @@ extern "C" {
     pub fn pt_render_samples(ctx: *mut pt_context, stratum_begin: u32, stratum_end: u32, seed: u64, out: *mut f32) -> i32;
     pub fn pt_generate_rays(ctx: *mut pt_context, stratum: u32, seed: u64, rays: *mut f32) -> i32;
     pub fn pt_trace_first_hit(ctx: *mut pt_context, rays: *const f32, n: u64, out: *mut pt_hit) -> i32;
+    pub fn pt_trace_first_hit_at(ctx: *mut pt_context, rays: *const f32, times: *const f32, n: u64, out: *mut pt_hit) -> i32;
     pub fn pt_trace_first_hit_static(ctx: *mut pt_context, rays_device: *const f32, n: u64, out_device: *mut pt_hit) -> i32;
     pub fn pt_light_pdf(ctx: *mut pt_context, rays: *const f32, n: u64, tris_by_solid_angle: i32, out: *mut f32) -> i32;
     pub fn pt_material_probe(ctx: *mut pt_context, material: i32, seed: u64, r#in: *const pt_material_probe_in, n: u64, out: *mut pt_material_probe_out) -> i32;

@@ -43,7 +43,8 @@ enum {
     PT_ERR_STATE = 5        /* call order: render before upload_scene / set_camera */
 };
 
-enum { PT_PRIM_TRI = 0, PT_PRIM_SPHERE = 1, PT_PRIM_QUAD = 2, PT_PRIM_INSTANCE = 3 };
+enum { PT_PRIM_TRI = 0, PT_PRIM_SPHERE = 1, PT_PRIM_QUAD = 2, PT_PRIM_INSTANCE = 3,
+       PT_PRIM_MOVING_SPHERE = 4 /* only in pt_hit::prim_type, as pt_trace_first_hit_at reports it */ };
 
 /* One node of InnerPrimitiveBuffer::bvh (FlatBVHNode, src/bvh.rs:667-679) in 32 bytes.
  * The left child of an interior node is the next node of the array (src/bvh.rs:495). */
@@ -227,6 +228,12 @@ int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *ra
 
 /* PrimitiveBuffer::hit for n caller-supplied rays: rays[n][8] as above, out[n] (host memory). */
 int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out);
+
+/* As pt_trace_first_hit, in a scene with moving spheres (pts_moving_sphere, not in the reference), which
+ * pt_trace_first_hit does not see: times[n] = the time in [0, 1] at which each ray is traced (NULL: all 0).  The
+ * moving spheres are tested after everything else, in index order, where they are at that time, as the renderer
+ * does for a path of that time; a hit on moving sphere k has prim_type PT_PRIM_MOVING_SPHERE, prim_id k. */
+int pt_trace_first_hit_at(pt_context *ctx, const float *rays, const float *times, uint64_t n, pt_hit *out);
 
 /* No counterpart in the reference.  pt_trace_first_hit for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels,

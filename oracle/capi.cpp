@@ -198,6 +198,33 @@ void pto_trace(const pto_scene *s, const float *rays, uint64_t n, int32_t *ids, 
 }
 
 
+// As pto_trace (single-threaded), then the moving spheres where they are at times[i] (null: time 0), after
+// everything else and in index order, as Scene::hit_scene does for a path of that time; a hit on moving sphere
+// k is reported as prim_type 4, prim_id k.
+void pto_trace_at(const pto_scene *s, const float *rays, const float *times, uint64_t n, int32_t *ids, float *tuv) {
+    for (uint64_t i = 0; i < n; i++) {
+        const float *r = rays + 8 * i;
+        Ray ray{v3(r[0], r[1], r[2]), v3(r[3], r[4], r[5]), r[6], r[7]};
+        HitRecord rec;
+        bool any = s->sc->objects.hit(ray, rec);
+        int32_t type = any ? rec.prim_type : -1, id = any ? rec.prim_id : -1, inst = any ? rec.inst_id : -1;
+        float t = any ? rec.t : ray.t_max, bu = any ? rec.bary_u : 0.0f, bv = any ? rec.bary_v : 0.0f;
+        const float time = times ? times[i] : 0.0f;
+        for (size_t k = 0; k < s->sc->moving.size(); k++) {
+            const pts_moving_sphere &m = s->sc->moving[k];
+            V3 c0 = v3(m.center0[0], m.center0[1], m.center0[2]), c1 = v3(m.center1[0], m.center1[1], m.center1[2]);
+            Sphere sp = Sphere::make(c0 + time * (c1 - c0), m.radius, m.material);
+            HitRecord h;
+            if (sp.hit(ray, h)) {
+                type = 4; id = (int32_t)k; inst = -1;
+                t = h.t; bu = bv = 0.0f;
+            }
+        }
+        ids[3 * i] = type; ids[3 * i + 1] = id; ids[3 * i + 2] = inst;
+        tuv[3 * i] = t; tuv[3 * i + 1] = bu; tuv[3 * i + 2] = bv;
+    }
+}
+
 // As pto_trace, single-threaded, and additionally returns the number of AABB tests and
 // primitive tests each ray caused: per_ray[n][2]; stack_hist[65] (may be null) = number of BVH
 // traversals whose deepest stack had k entries.

@@ -45,6 +45,8 @@ def lib() -> C.CDLL:
         L.pto_primary_rays.argtypes = [C.c_void_p, C.c_void_p]
         L.pto_sample_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.pto_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.pto_trace_at.restype = None
+        L.pto_trace_at.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.pto_trace_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pto_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -160,6 +162,16 @@ class OracleScene:
         ctr = np.zeros(5, np.uint64) if counters else None
         lib().pto_trace(self.h, _p(rays), n, _p(ids), _p(tuv), _p(ctr), threads)
         return (ids, tuv, ctr) if counters else (ids, tuv)
+
+    def trace_at(self, rays: np.ndarray, times: Optional[np.ndarray] = None):
+        """Closest hits including the moving spheres at the given times (prim_type 4, prim_id = index of the moving sphere)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        n = rays.shape[0]
+        times = None if times is None else np.ascontiguousarray(times, np.float32)
+        ids = np.zeros((n, 3), np.int32)
+        tuv = np.zeros((n, 3), np.float32)
+        lib().pto_trace_at(self.h, _p(rays), _p(times), n, _p(ids), _p(tuv))
+        return ids, tuv
 
     def trace_counts(self, rays: np.ndarray):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)

@@ -93,7 +93,7 @@ PROBE_OUT_DTYPE = np.dtype([("w_in", np.float32, 3), ("draws", np.uint32), ("bsd
 
 # every symbol include/ptcore.h and include/pthost.h declare
 CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt_upload_scene", "pt_set_camera", "pt_render", "pt_sync",
-                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_trace_first_hit_static", "pt_light_pdf", "pt_material_probe", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
+                "pt_render_samples", "pt_generate_rays", "pt_trace_first_hit", "pt_trace_first_hit_at", "pt_trace_first_hit_static", "pt_light_pdf", "pt_material_probe", "pt_read_accum", "pt_read_rgb8", "pt_reset_accum", "pt_read_triangle_order",
                 "pt_copy_accum_to_device", "pt_set_accum_from_device", "pt_stats_get", "pt_stats_reset",
                 "pt_group_create", "pt_group_destroy", "pt_group_last_error", "pt_group_size", "pt_group_member", "pt_group_split", "pt_group_set_option",
                 "pt_group_upload_scene", "pt_group_set_camera", "pt_group_render", "pt_group_sync", "pt_group_read_accum", "pt_group_read_rgb8",
@@ -121,6 +121,7 @@ def core_lib() -> C.CDLL:
         L.pt_render_samples.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, vp]
         L.pt_generate_rays.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
         L.pt_trace_first_hit.argtypes = [vp, vp, C.c_uint64, vp]
+        L.pt_trace_first_hit_at.argtypes = [vp, vp, vp, C.c_uint64, vp]
         L.pt_trace_first_hit_static.argtypes = [vp, vp, C.c_uint64, vp]
         L.pt_light_pdf.argtypes = [vp, vp, C.c_uint64, C.c_int, vp]
         L.pt_material_probe.argtypes = [vp, C.c_int32, C.c_uint64, vp, C.c_uint64, vp]
@@ -354,6 +355,15 @@ class Renderer:
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
         out = np.zeros(rays.shape[0], HIT_DTYPE)
         self._check(self.L.pt_trace_first_hit(self.ctx, rays.ctypes.data_as(C.c_void_p), rays.shape[0], out.ctypes.data_as(C.c_void_p)), "pt_trace_first_hit")
+        return out
+
+    def trace_at(self, rays: np.ndarray, times: Optional[np.ndarray] = None) -> np.ndarray:
+        """pt_trace_first_hit_at: closest hits with the moving spheres where they are at times[i] (None: time 0)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        t = None if times is None else np.ascontiguousarray(times, np.float32)
+        out = np.zeros(rays.shape[0], HIT_DTYPE)
+        self._check(self.L.pt_trace_first_hit_at(self.ctx, rays.ctypes.data_as(C.c_void_p), None if t is None else t.ctypes.data_as(C.c_void_p), rays.shape[0],
+                                                 out.ctypes.data_as(C.c_void_p)), "pt_trace_first_hit_at")
         return out
 
     def trace_static(self, rays_device: int, n: int, out_device: int):

@@ -851,6 +851,28 @@ __global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps,
         ps.hit2[i] = h.code;
     }
 }
+// The moving spheres, where they are at times[i] (null: time 0), against ray i with the hit and t_max the static
+// scene left: the last line of the renderer's closest-hit step, for caller-supplied rays.
+__global__ __launch_bounds__(BLOCK) void k_trace_moving(DevScene sc, PathState ps, uint32_t n, const float *times) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i], h4 = ps.hit[i];
+        HitState h;
+        h.u = h4.y;
+        h.v = h4.z;
+        h.prim = __float_as_uint(h4.w);
+        h.code = ps.hit2[i];
+        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, h4.x);
+        const float time = times ? times[i] : 0.0f;
+        for (uint32_t k = 0; k < sc.n_moving; k++) {
+            const uint32_t g = sc.n_static_spheres + k;
+            const float4 sp = sc.spheres[g], dl = sc.moving_delta[k];
+            const f3 c = mk3(sp.x, sp.y, sp.z) + time * mk3(dl.x, dl.y, dl.z);
+            hit_sphere(make_float4(c.x, c.y, c.z, sp.w), g, r, h, 0u);
+        }
+        ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+        ps.hit2[i] = h.code;
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_trace_out(DevScene sc, PathState ps, uint32_t n, pt_hit *out) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const float4 h4 = ps.hit[i];
@@ -872,6 +894,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_out(DevScene sc, PathState ps, 
             if (inst1) set = &sc.sets[__float_as_uint(sc.insts[7 * (size_t)(sc.world.insts.prim_first + inst1 - 1u) + 6].x)];
             const uint32_t first = (type == PT_PRIM_TRI) ? set->tris.prim_first : ((type == PT_PRIM_SPHERE) ? set->spheres.prim_first : set->quads.prim_first);
             o.prim_id = (int32_t)(prim - first);
+            if (type == PT_PRIM_SPHERE && sc.n_moving != 0u && prim >= sc.n_static_spheres) {  // belongs to no set
+                o.prim_type = PT_PRIM_MOVING_SPHERE;
+                o.prim_id = (int32_t)(prim - sc.n_static_spheres);
+            }
         }
         out[i] = o;
     }

@@ -586,7 +586,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
             if (bufs[t]->node_count && !nodes_ok(s->nodes + bufs[t]->node_first, bufs[t]->node_count, bufs[t]->prim_count, why))
                 return fail(ctx, PT_ERR_INVALID, "set %u buffer %d: %s", k, t, why.c_str());
         if (k >= 1 && ps.instances.prim_count && k != 1)
-            return fail(ctx, PT_ERR_UNSUPPORTED, "set %u: instances nested inside an instance are not supported", k);
+            return fail(ctx, PT_ERR_UNSUPPORTED, "set %u: instances inside an instance: lift them to the top level with composed transforms first (libpthost does)", k);
     }
     for (uint32_t i = 0; i < s->n_instances; i++) {
         const pt_instance_desc &in = s->instances[i];
@@ -1534,7 +1534,8 @@ int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *ra
     return PT_OK;
 }
 
-int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out) {
+// PrimitiveBuffer::hit for caller-supplied rays; with_moving: then the moving spheres at times[i] (null: time 0).
+static int trace_first_hit(pt_context *ctx, const float *rays, const float *times, bool with_moving, uint64_t n, pt_hit *out) {
     if (!ctx) return PT_ERR_INVALID;
     if (!ctx->have_scene) return fail(ctx, PT_ERR_STATE, "upload a scene before tracing");
     if (n == 0) return PT_OK;
@@ -1544,16 +1545,20 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     pt_context::Pipe &pp = ctx->pipes[0];
     int rc = ensure_paths(ctx, pp, n);
     if (rc) return rc;
-    float *d_rays = nullptr;
+    with_moving = with_moving && ctx->scene.n_moving != 0;
+    float *d_rays = nullptr, *d_times = nullptr;
     pt_hit *d_out = nullptr;
     hipError_t e = hipMalloc((void **)&d_rays, n * 8 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(pt_hit));
+    if (e == hipSuccess && with_moving && times) e = hipMalloc((void **)&d_times, n * sizeof(float));
     if (e != hipSuccess) {
         if (d_rays) (void)hipFree(d_rays);
+        if (d_out) (void)hipFree(d_out);
         return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
     }
     hipStream_t st = ctx->stream;
     e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && d_times) e = hipMemcpyAsync(d_times, times, n * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, pp.ps, (uint32_t)n);
         const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
@@ -1565,6 +1570,7 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
             hipLaunchKernelGGL(k_trace, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
             if (insts) hipLaunchKernelGGL(k_trace_inst, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         }
+        if (with_moving) hipLaunchKernelGGL(k_trace_moving, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, pp.ps, (uint32_t)n, d_times);
         hipLaunchKernelGGL(k_trace_out, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, pp.ps, (uint32_t)n, d_out);
         e = hipMemcpyAsync(out, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost, st);
     }
@@ -1572,8 +1578,13 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
     if (e == hipSuccess) e = hipGetLastError();
     (void)hipFree(d_rays);
     (void)hipFree(d_out);
+    if (d_times) (void)hipFree(d_times);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
     return sync_all(ctx);
+}
+int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out) { return trace_first_hit(ctx, rays, nullptr, false, n, out); }
+int pt_trace_first_hit_at(pt_context *ctx, const float *rays, const float *times, uint64_t n, pt_hit *out) {
+    return trace_first_hit(ctx, rays, times, true, n, out);
 }
 
 // ---------------------------------------------------------------- first hits without allocating

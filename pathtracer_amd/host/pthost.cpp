@@ -702,7 +702,9 @@ pt_buffer_desc FlatScene::add_nodes(const InnerPrimitiveBuffer<T> &b, uint32_t p
     nodes_.insert(nodes_.end(), b.bvh.begin(), b.bvh.end());
     return d;
 }
-uint32_t FlatScene::add_set(const PrimitiveBuffer &pb) {
+// instances: the instance buffer to describe for this set; null = none (the set of an instance: the device
+// library searches two levels, and build() has lifted deeper instances to the top one).
+uint32_t FlatScene::add_set(const PrimitiveBuffer &pb, const InnerPrimitiveBuffer<Instance> *instances) {
     const uint32_t index = (uint32_t)sets_.size();
     sets_.push_back(pt_primset_desc{});
     pt_primset_desc d{};
@@ -724,12 +726,17 @@ uint32_t FlatScene::add_set(const PrimitiveBuffer &pb) {
         quads_.insert(quads_.end(), v, v + 17);
         quad_mat_.push_back(material_index(q.mat));
     }
-    d.instances = add_nodes(pb.instances, (uint32_t)instances_.size());
+    if (!instances) {
+        d.instances = pt_buffer_desc{(uint32_t)instances_.size(), 0u, (uint32_t)nodes_.size(), 0u};
+        sets_[index] = d;
+        return index;
+    }
+    d.instances = add_nodes(*instances, (uint32_t)instances_.size());
     const size_t inst_first = instances_.size();
-    instances_.resize(inst_first + pb.instances.buffer.size());
+    instances_.resize(inst_first + instances->buffer.size());
     sets_[index] = d;
-    for (size_t k = 0; k < pb.instances.buffer.size(); k++) {
-        const Instance &in = pb.instances.buffer[k];
+    for (size_t k = 0; k < instances->buffer.size(); k++) {
+        const Instance &in = instances->buffer[k];
         pt_instance_desc id{};
         std::memcpy(id.transform, in.transform.m, sizeof id.transform);
         std::memcpy(id.inverse, in.inverse.m, sizeof id.inverse);
@@ -758,19 +765,48 @@ void FlatScene::add_moving_sphere(Point3 center0, Point3 center1, float radius, 
     moving_.push_back(m);
 }
 
+// An Instance holds a whole PrimitiveBuffer (src/objects.rs:281-286), which may hold instances again.  The device
+// library searches two levels, so instances inside instances are lifted to the top level with their transforms
+// composed: Instance::hit of the outer one takes the ray through `inverse`, the inner one through its own
+// (src/objects.rs:385-390), and the way back goes through the two `transform`s in the opposite order (:393-394),
+// so the lifted instance carries transform = outer * inner and inverse = inner^-1 * outer^-1.  Results equal the
+// nested evaluation up to the rounding of the matrix products; which of several hits at exactly the same
+// distance wins may differ, because the lifted instances are visited in the order of their own place in the top
+// level's instance buffer (and its BVH, rebuilt over the longer list) rather than inside the outer instance.
+static void lift_instances(const Instance &in, const Matrix4 &transform, const Matrix4 &inverse, int depth, InnerPrimitiveBuffer<Instance> &out) {
+    if (depth > 8) throw std::runtime_error("instance nesting too deep");
+    const PrimitiveBuffer &child = *in.obj;
+    if (child.triangles.len() + child.spheres.len() + child.quads.len() > 0 || child.instances.len() == 0) {
+        Instance flat;
+        flat.obj = in.obj;  // described without its instance buffer
+        flat.transform = transform;
+        flat.inverse = inverse;
+        out.push(std::move(flat));
+    }
+    for (const Instance &inner : child.instances.buffer) lift_instances(inner, transform * inner.transform, inner.inverse * inverse, depth + 1, out);
+}
+
 void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights) {
-    add_set(objects);
-    add_set(lights.objects);
+    bool nested = false;
+    for (const Instance &in : objects.instances.buffer) nested = nested || in.obj->instances.len() > 0;
+    InnerPrimitiveBuffer<Instance> lifted;
+    if (nested) {
+        for (const Instance &in : objects.instances.buffer) lift_instances(in, in.transform, in.inverse, 0, lifted);
+        if (!objects.instances.bvh.empty() && !BVHBuilder::build(lifted)) throw std::runtime_error("BVHBuilder::build failed: tree deeper than 63 levels");
+    }
+    const InnerPrimitiveBuffer<Instance> &top = nested ? lifted : objects.instances;
+    add_set(objects, &top);
+    add_set(lights.objects, &lights.objects.instances);
     // children of the world's instances, in post-build instance order
     const pt_buffer_desc wi = sets_[0].instances;
     for (uint32_t k = 0; k < wi.prim_count; k++) {
-        const uint32_t child = add_set(*objects.instances.buffer[k].obj);
+        const uint32_t child = add_set(*top.buffer[k].obj, nullptr);
         instances_[wi.prim_first + k].child_set = child;
     }
     // instances listed as lights keep a child set too, although the integrator never enters it
     const pt_buffer_desc li = sets_[1].instances;
     for (uint32_t k = 0; k < li.prim_count; k++) {
-        const uint32_t child = add_set(*lights.objects.instances.buffer[k].obj);
+        const uint32_t child = add_set(*lights.objects.instances.buffer[k].obj, nullptr);
         instances_[li.prim_first + k].child_set = child;
     }
     // moving spheres go behind the spheres of the sets, as they are at time 0

@@ -272,7 +272,7 @@ public:
     void add_moving_sphere(Point3 center0, Point3 center1, float radius, const MaterialRef &material);
 
 private:
-    uint32_t add_set(const PrimitiveBuffer &pb);
+    uint32_t add_set(const PrimitiveBuffer &pb, const InnerPrimitiveBuffer<Instance> *instances);
     template <class T>
     pt_buffer_desc add_nodes(const InnerPrimitiveBuffer<T> &b, uint32_t prim_first);
     std::vector<float> tri_data_, spheres_, quads_;

@@ -2,8 +2,9 @@
 
 ``cornell`` restates ``src/scenes/cornell.rs``; ``knob`` restates ``src/scenes/object.rs``
 with a procedural stand-in for ``mitsuba_smooth.obj`` (the reference ignores ``*.obj`` in
-git, so the asset is not available); ``lucy_like``, ``dragon_box`` and ``interior`` are
-procedural scenes for the remaining benchmark configurations.  Procedural geometry uses
+git, so the asset is not available); ``lucy`` restates ``src/scenes/lucy.rs`` (camera, light,
+materials) around a procedural stand-in for the author's local ``sponza_tri.obj``; ``dragon_box``,
+``interior`` and ``next_week_like`` are procedural scenes for the remaining benchmark configurations.  Procedural geometry uses
 only a hash-based noise and float64 trigonometry rounded to float32.
 """
 from __future__ import annotations
@@ -217,6 +218,78 @@ def knob(width: int = 768, spp: int = 10240, max_depth: int = 50, seed: int = 1,
     s.objects.build_bvh = True
     s.camera = CameraSrc(1.0, width, 15.0, (2.0, 10.0, 16.0), (0.0, 1.0, 0.0), 10.0, 0.0, spp, max_depth,
                          (0.0, 0.0, 0.0))
+    return s
+
+
+# --------------------------------------------------------------------------- src/scenes/lucy.rs
+def lucy_meshes(seed: int = 1, detail: float = 1):
+    """Stand-in for ``sponza_tri.obj`` (``lucy.rs:21`` names a path on the author's machine): an open courtyard in
+    front of the camera of ``lucy.rs:51-72`` — a tessellated floor, two arcades of columns carrying a lintel, and a
+    back wall — as separate meshes, the way ``TriMesh::load_as_vec`` returns one mesh per model of the file."""
+    meshes = []
+    nx, nz = _scaled(160, detail), _scaled(64, detail)
+    xs, zs = np.linspace(-6.0, 34.0, nx + 1), np.linspace(-9.0, 9.0, nz + 1)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = 0.03 * _value_noise(X * 0.4, Z * 0.4, 8, seed)  # worn flagstones
+    P = np.stack([X, Y, Z], axis=-1)
+    N = np.stack([np.zeros_like(X), np.ones_like(X), np.zeros_like(X)], axis=-1)
+    UV = np.stack([(X + 6.0) / 40.0, (Z + 9.0) / 18.0], axis=-1)
+    meshes.append(_grid_to_tris(P, N, UV))
+    nt, nh = _scaled(48, detail), _scaled(24, detail)
+    for side in (-1.0, 1.0):
+        for k in range(9):
+            cx, cz = -2.0 + 4.0 * k, side * 6.0
+            tt, hh = np.linspace(0, 2 * np.pi, nt + 1), np.linspace(0.0, 5.0, nh + 1)
+            Hh, Tt = np.meshgrid(hh, tt, indexing="ij")
+            rad = 0.45 + 0.03 * np.cos(10 * Tt) + 0.1 * np.exp(-((Hh - 0.2) ** 2) * 10) + 0.1 * np.exp(-((Hh - 4.8) ** 2) * 10)
+            P = np.stack([cx + rad * np.cos(Tt), Hh, cz + rad * np.sin(Tt)], axis=-1)
+            N = np.stack([np.cos(Tt), np.zeros_like(Tt), np.sin(Tt)], axis=-1)
+            UV = np.stack([Tt / (2 * np.pi), Hh / 5.0], axis=-1)
+            meshes.append(_grid_to_tris(P, N, UV, flip=True))
+        # lintel over the arcade: a long box as a closed grid of four faces
+        z0, z1 = side * 6.0 - 0.6, side * 6.0 + 0.6
+        corners = np.array([[z0, 5.0], [z1, 5.0], [z1, 5.8], [z0, 5.8], [z0, 5.0]])
+        xs2 = np.linspace(-3.0, 31.0, _scaled(34, detail) + 1)
+        P = np.stack([np.broadcast_to(xs2[:, None], (xs2.size, 5)), np.broadcast_to(corners[None, :, 1], (xs2.size, 5)),
+                      np.broadcast_to(corners[None, :, 0], (xs2.size, 5))], axis=-1).astype(np.float64)
+        nrm_ring = np.array([[0, -1, 0], [0, 0, 1], [0, 1, 0], [0, 0, -1], [0, -1, 0]], np.float64)
+        N = np.broadcast_to(nrm_ring[None, :, :], P.shape)
+        UV = np.stack([np.broadcast_to(((xs2 + 3.0) / 34.0)[:, None], (xs2.size, 5)), np.broadcast_to(np.linspace(0, 1, 5)[None, :], (xs2.size, 5))], axis=-1)
+        meshes.append(_grid_to_tris(P, N, UV))
+    ny = _scaled(40, detail)
+    ys, zs = np.linspace(0.0, 9.0, ny + 1), np.linspace(-9.0, 9.0, nz + 1)
+    Yy, Zz = np.meshgrid(ys, zs, indexing="ij")
+    Xx = 34.0 + 0.05 * _value_noise(Yy * 0.5, Zz * 0.5, 6, seed + 1)
+    P = np.stack([Xx, Yy, Zz], axis=-1)
+    N = np.stack([-np.ones_like(Xx), np.zeros_like(Xx), np.zeros_like(Xx)], axis=-1)
+    UV = np.stack([(Zz + 9.0) / 18.0, Yy / 9.0], axis=-1)
+    meshes.append(_grid_to_tris(P, N, UV))
+    return meshes
+
+
+def lucy(width: int = 1200, spp: int = 51200, max_depth: int = 16, seed: int = 1, detail: float = 1, asset: Optional[str] = None) -> SceneSource:
+    """``Lucy::build_scene`` / ``build_camera`` (``src/scenes/lucy.rs:16-75``): every mesh of the .obj file with the
+    grey Lambertian ``mat2`` (``:39-44``), a small sphere light of radiance 255 (``:24, :33-36``), a sky of 1.5
+    (``:70``), 16:9 at 1200 pixels, 51200 -> 226^2 samples, depth 16 (``:51-60``).  ``asset``: the .obj file; without
+    one, the procedural courtyard of ``lucy_meshes``."""
+    s = SceneSource()
+    s.name = "lucy"
+    s.metal((0.3, 0.3, 0.8), 0.1)                        # "ground" (its sphere is commented out, lucy.rs:27-31, :37)
+    emit = s.diffuse_light((255.0, 255.0, 255.0))
+    s.dielectric(1.5)                                    # "mat1" (unused)
+    mat2 = s.lambertian((0.5, 0.5, 0.5))
+    s.lights.add_sphere((0.7, 2.3, 1.0), 0.5, emit)
+    s.objects.add_sphere((0.7, 2.3, 1.0), 0.5, emit)
+    if asset is not None:
+        from .core import load_obj
+        meshes = load_obj(asset)
+    else:
+        meshes = lucy_meshes(seed, detail)
+    for pos, nrm, uv in meshes:
+        if pos.shape[0]:
+            s.objects.add_triangles(pos, nrm, uv, mat2)
+    s.objects.build_bvh = True  # main.rs:72 builds the BVHs of whichever scene it renders
+    s.camera = CameraSrc(16.0 / 9.0, width, 20.0, (-12.0, 18.0, 0.0), (20.0, 0.4, 0.0), 10.0, 0.0, spp, max_depth, (1.5, 1.5, 1.5))
     return s
 
 

@@ -32,14 +32,15 @@ def _random_rays(rng, n, lo, hi, special=True):
     return r
 
 
-@pytest.mark.parametrize("name", ["small_mixed", "knob", "next_week_like", "interior"])
+@pytest.mark.parametrize("name", ["small_mixed", "knob", "next_week_like", "interior", "lucy"])
 def test_random_and_degenerate_rays_both_traversals(name):
     from pathtracer_amd.core import PT_OPT_TRAVERSAL
     src = {"small_mixed": lambda: scenes.small_mixed(32, 16), "knob": lambda: scenes.knob(32, 16),
-           "next_week_like": lambda: scenes.next_week_like(32, 16), "interior": lambda: scenes.interior(32, 16, n_lights=16, columns=3)}[name]()
+           "next_week_like": lambda: scenes.next_week_like(32, 16), "interior": lambda: scenes.interior(32, 16, n_lights=16, columns=3),
+           "lucy": lambda: scenes.lucy(32, 16, detail=0.5)}[name]()
     o, r = _pair(src)
     rng = np.random.default_rng(5)
-    box = {"small_mixed": (-7, 9), "knob": (-3, 4), "next_week_like": (-300, 700), "interior": (0.5, 15)}[name]
+    box = {"small_mixed": (-7, 9), "knob": (-3, 4), "next_week_like": (-300, 700), "interior": (0.5, 15), "lucy": (-8, 20)}[name]
     rays = _random_rays(rng, 60000, *box)
     # rays that start exactly on surfaces (what every bounce ray does)
     ids0, tuv0 = o.trace(rays)
@@ -79,10 +80,11 @@ def test_traversal_counters_equal_the_oracles_on_identical_rays():
         assert (st["node_tests"], st["tri_tests"], st["sphere_tests"], st["quad_tests"]) == tuple(int(x) for x in ctr[:4]), src.name
 
 
-@pytest.mark.parametrize("name,prob", [("cornell", 1.0), ("small_mixed", 1.0), ("small_mixed", 0.5), ("cornell", 0.25)])
+@pytest.mark.parametrize("name,prob", [("cornell", 1.0), ("small_mixed", 1.0), ("small_mixed", 0.5), ("cornell", 0.25), ("lucy", 1.0), ("lucy", 0.5)])
 def test_per_sample_radiance_with_and_without_light_sampling(name, prob):
     from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY
-    src = scenes.cornell(48, 16) if name == "cornell" else scenes.small_mixed(48, 16)
+    src = {"cornell": lambda: scenes.cornell(48, 16), "small_mixed": lambda: scenes.small_mixed(48, 16),
+           "lucy": lambda: scenes.lucy(64, 16, detail=0.5)}[name]()  # lucy.rs: 16:9, sky 1.5, sphere light of radiance 255
     o, r = _pair(src)
     o.set_bsdf_probability(prob)
     r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, prob)

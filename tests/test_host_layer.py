@@ -33,11 +33,11 @@ def _compare(src):
     return o, h
 
 
-@pytest.mark.parametrize("name", ["cornell", "small_mixed", "knob", "next_week_like", "interior"])
+@pytest.mark.parametrize("name", ["cornell", "small_mixed", "knob", "next_week_like", "interior", "lucy"])
 def test_builder_and_derived_quantities_match_oracle(name):
     src = {"cornell": lambda: scenes.cornell(64, 16), "small_mixed": lambda: scenes.small_mixed(32, 16),
            "knob": lambda: scenes.knob(32, 16), "next_week_like": lambda: scenes.next_week_like(32, 16),
-           "interior": lambda: scenes.interior(32, 16, n_lights=12, columns=2)}[name]()
+           "interior": lambda: scenes.interior(32, 16, n_lights=12, columns=2), "lucy": lambda: scenes.lucy(32, 16, detail=0.5)}[name]()
     _compare(src)
 
 

@@ -83,3 +83,38 @@ def test_modes_that_do_not_handle_moving_spheres_say_so():
         r.set_option(key, 1)
         with pytest.raises(PtError):
             r.render(0, 1, seed=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["moving", "next_week"])
+def test_first_hits_with_moving_spheres_at_given_times(which):
+    """pt_trace_first_hit_at against the oracle: the static scene first, then the moving spheres where they are at each
+    ray's time, bit for bit; pt_trace_first_hit keeps ignoring them."""
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd import scenes
+    from pathtracer_amd.core import HostScene, Renderer
+    src = (_scene((-1.5, 0.0, 0.0), (1.5, 0.3, 0.5), width=64, spp=4, depth=4, extras=True) if which == "moving"
+           else scenes.next_week_like(64, 4, extensions=True))
+    o = OracleScene(src)
+    r = Renderer(HostScene(src))
+    rng = np.random.default_rng(12)
+    rays = np.tile(o.primary_rays(), (3, 1))
+    times = rng.uniform(0.0, 1.0, rays.shape[0]).astype(np.float32)
+    times[:64] = 0.0
+    times[64:128] = 1.0
+    ids, tuv = o.trace_at(rays, times)
+    h = r.trace_at(rays, times)
+    assert (ids[:, 0] == 4).sum() > 50, "some rays must meet a moving sphere"
+    assert np.array_equal(h["prim_type"], ids[:, 0]) and np.array_equal(h["prim_id"], ids[:, 1]) and np.array_equal(h["inst_id"], ids[:, 2])
+    assert np.array_equal(h["t"].view(np.uint32), tuv[:, 0].view(np.uint32))
+    # the same rays at different times meet the sphere in different places
+    assert len(np.unique(tuv[ids[:, 0] == 4, 0])) > 20
+    # without times: time 0 for every ray
+    ids0, tuv0 = o.trace_at(rays, None)
+    h0 = r.trace_at(rays, None)
+    assert np.array_equal(h0["prim_type"], ids0[:, 0]) and np.array_equal(h0["t"].view(np.uint32), tuv0[:, 0].view(np.uint32))
+    # the plain query does not see them (its rays are not paths, they have no time)
+    ids_s, tuv_s = o.trace(rays)
+    hs = r.trace(rays)
+    assert np.array_equal(hs["prim_type"], ids_s[:, 0]) and not (hs["prim_type"] == 4).any()
+    r.close()

@@ -1,0 +1,101 @@
+"""Instances inside instances (src/objects.rs:281-286: an Instance holds a whole PrimitiveBuffer, which has an
+instance buffer of its own).  The device library searches two levels; the host layer lifts deeper instances to the
+top level with composed transforms.  The oracle evaluates the nesting as the reference does, level by level."""
+import numpy as np
+import pytest
+
+from pathtracer_amd.core import HostScene
+from pathtracer_amd.scene_src import CameraSrc, InstanceSrc, PrimSet, SceneSource, new_box
+
+
+def nested_scene(width=48, spp=16, top_bvh=True) -> SceneSource:
+    s = SceneSource()
+    s.name = "nested"
+    red, green, blue, grey = s.lambertian((0.8, 0.2, 0.2)), s.lambertian((0.2, 0.8, 0.2)), s.lambertian((0.2, 0.3, 0.9)), s.lambertian((0.6, 0.6, 0.6))
+    mirror = s.metal((0.9, 0.9, 0.9), 0.0)
+    emit = s.diffuse_light((6.0, 6.0, 6.0))
+    # level 3: a few spheres
+    beads = PrimSet()
+    for k in range(5):
+        beads.add_sphere((0.35 * k, 0.0, 0.0), 0.15, blue if k % 2 else mirror)
+    beads.build_bvh = True
+    # level 2: a box with a string of beads on top, and a second string turned by 90 degrees
+    post = new_box((0.0, 0.0, 0.0), (0.4, 1.2, 0.4), green)
+    post.add_instance(InstanceSrc(beads).translate((-0.5, 1.35, 0.2)))
+    post.add_instance(InstanceSrc(beads).rotate_y(1.5707964).scale_uniform(0.8).translate((0.2, 1.7, 0.9)))
+    # level 1: two posts on a slab, and the slab's own geometry
+    slab = new_box((0.0, 0.0, 0.0), (4.0, 0.2, 2.0), red)
+    slab.add_sphere((3.5, 0.5, 1.0), 0.3, mirror)
+    slab.add_instance(InstanceSrc(post).translate((0.5, 0.2, 0.5)))
+    slab.add_instance(InstanceSrc(post).rotate_y(0.6).translate((2.4, 0.2, 1.2)))
+    only_nested = PrimSet()  # an instance whose set holds nothing but another instance
+    only_nested.add_instance(InstanceSrc(beads).scale((1.5, 1.0, 1.0)))
+    o = s.objects
+    o.add_quad((-8, 0, -8), (16, 0, 0), (0, 0, 16), grey)
+    o.add_quad((-2, 6, -2), (4, 0, 0), (0, 0, 4), emit)
+    s.lights.add_quad((-2, 6, -2), (4, 0, 0), (0, 0, 4), emit)
+    o.add_instance(InstanceSrc(slab).rotate_y(-0.3).translate((-2.0, 0.0, -1.0)))
+    o.add_instance(InstanceSrc(slab).scale_uniform(0.5).rotate_z(0.2).translate((-3.0, 1.5, 2.0)))
+    o.add_instance(InstanceSrc(only_nested).translate((1.0, 2.5, -2.0)))
+    o.add_instance(InstanceSrc(new_box((0, 0, 0), (0.8, 0.8, 0.8), blue)).translate((3.0, 0.0, 2.5)))  # an ordinary one
+    o.build_bvh = top_bvh
+    s.camera = CameraSrc(1.0, width, 45.0, (0.5, 4.0, -9.0), (0.0, 1.2, 0.0), 9.0, 0.0, spp, 8, (0.3, 0.35, 0.5))
+    return s
+
+
+def test_host_layer_lifts_nested_instances_with_composed_transforms():
+    from oracle.pyoracle import OracleScene
+    src = nested_scene()
+    h = HostScene(src)
+    # 2 slabs x (slab itself + 2 posts x (post itself + 2 bead strings)) + (only_nested: just its bead string) + 1 box
+    assert h.desc.n_instances == 2 * (1 + 2 * 3) + 1 + 1
+    world = h.set_desc(0)
+    assert world.instances.prim_count == h.desc.n_instances and world.instances.node_count > 0
+    for k in range(2, h.desc.n_sets):
+        assert h.set_desc(k).instances.prim_count == 0  # no set below the top level holds instances
+    inst = h.instances(world.instances)
+    for row in inst:  # transform and inverse stay inverses of each other, and affine
+        t, i = row[:16].reshape(4, 4).astype(np.float64), row[16:].reshape(4, 4).astype(np.float64)
+        assert np.allclose(t @ i, np.eye(4), atol=2e-5)
+        assert np.array_equal(row[12:16], [0, 0, 0, 1]) and np.array_equal(row[28:32], [0, 0, 0, 1])
+    # a scene without nesting is described exactly as before: same instances in the builder's order as the oracle's
+    from pathtracer_amd import scenes
+    plain = scenes.cornell(32, 4)
+    assert np.array_equal(HostScene(plain).instances(HostScene(plain).set_desc(0).instances).view(np.uint32), OracleScene(plain).instances(0).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_bvh", [True, False])
+def test_nested_instances_first_hits_and_radiance_against_the_oracle(top_bvh):
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import Renderer
+    src = nested_scene(top_bvh=top_bvh)
+    o = OracleScene(src)
+    r = Renderer(HostScene(src), device=0)
+    rng = np.random.default_rng(4)
+    n = 40_000
+    org = rng.uniform(-6, 6, (n, 3)).astype(np.float32) + np.array([0, 5, 0], np.float32)
+    tgt = rng.uniform(-3.5, 3.5, (n, 3)).astype(np.float32) * np.array([1, 0.4, 1], np.float32) + np.array([0, 1.2, 0], np.float32)
+    rays = np.concatenate([org, tgt - org, np.full((n, 1), 0.001, np.float32), np.full((n, 1), np.inf, np.float32)], axis=1)
+    rays = np.concatenate([rays, o.primary_rays()])
+    ids, tuv = o.trace(rays)
+    h = r.trace(rays)
+    nested_hits = (ids[:, 2] >= 0).sum()
+    assert nested_hits > 3000
+    # the composed matrices round differently from two successive transforms: distances agree to a few ulps of the
+    # scene's scale, and a ray may pick the other of two surfaces that lie within that of each other
+    hit_o, hit_d = ids[:, 0] >= 0, h["prim_type"] >= 0
+    assert (hit_o != hit_d).mean() < 2e-4
+    both = hit_o & hit_d
+    close = np.abs(h["t"][both] - tuv[both, 0]) <= 2e-5 * np.maximum(1.0, np.abs(tuv[both, 0]))
+    assert close.mean() > 0.998, close.mean()  # grazing rays may pick the other of two nearby surfaces
+    assert (h["prim_type"][both] != ids[both, 0]).mean() < 5e-4
+    # rays that meet no instance at all are untouched by the lifting: bit-identical
+    plain = both & (ids[:, 2] < 0) & (h["inst_id"] < 0)
+    assert plain.sum() > 1000 and np.array_equal(h["t"][plain].view(np.uint32), tuv[plain, 0].view(np.uint32))
+    got = np.nan_to_num(r.render_samples(0, 16, seed=8), nan=0.0, posinf=0.0, neginf=0.0)
+    want = np.nan_to_num(o.render(0, 16, seed=8, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    agree = np.all(np.abs(got - want) <= 1e-3 * np.maximum(1.0, np.abs(want)), axis=-1)
+    assert agree.mean() > 0.98, agree.mean()
+    assert abs(got.mean() - want.mean()) < 0.02 * want.mean()
+    r.close()

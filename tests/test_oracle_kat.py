@@ -392,3 +392,18 @@ def test_vndf_sample_from_the_normal():
         got, n = o.material_scatter(m["metal"], (0, 1, 0), seed=9, pixel=pixel, stratum=2)
         assert n == 2
         assert np.allclose(got, want, atol=3e-6)
+
+
+def test_camera_constants_lucy():
+    # src/scenes/lucy.rs:51-72 through Camera::new (src/camera.rs:79-144): 16:9 at 1200 -> 675 rows, 51200 -> 226^2 samples
+    o = po.OracleScene(scenes.lucy(detail=0.25))
+    k = o.camera_constants()
+    assert (int(k[0]), int(k[1]), int(k[21]), int(k[23])) == (1200, 675, 226, 16)
+    assert np.allclose(k[2:5], [-12.0, 18.0, 0.0]) and np.allclose(k[24:27], [1.5, 1.5, 1.5])
+    # the view direction: w = normalize(from - at); pixel_du is along u = normalize(vup x w), of length viewport_u / W
+    w = np.array([-12.0 - 20.0, 18.0 - 0.4, 0.0]); w /= np.linalg.norm(w)
+    u = np.cross([0.0, 1.0, 0.0], w); u /= np.linalg.norm(u)
+    h = math.tan(math.radians(20.0) / 2.0)
+    viewport_u = 2.0 * h * 10.0 * (1200.0 / 675.0)
+    assert np.allclose(k[8:11], u * viewport_u / 1200.0, rtol=2e-6, atol=1e-9)
+    assert abs(k[22] - 1.0 / 226.0) < 1e-9
