@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--tail-below", type=int, default=-1)
     ap.add_argument("--rolling", type=int, default=12_000_000,
                     help="paths started per launch of the rolling schedule (0: one batch at a time per pipe; -1: library default)")
+    ap.add_argument("--live-factor", type=float, default=0.0, help="rays in flight a pipe has room for, as a multiple of the paths started per launch (0: library default)")
     ap.add_argument("--integrator", default="reference", choices=["reference", "nee"],
                     help="nee: next-event estimation with shadow rays (not in the reference); no counted pass, so no roofline figure")
     ap.add_argument("--bsdf-probability", type=float, default=1.0,
@@ -86,7 +87,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -116,6 +117,8 @@ def main():
         r.set_option(PT_OPT_TAIL_BELOW, args.tail_below)
     if args.rolling >= 0:
         r.set_option(PT_OPT_ROLLING, args.rolling)
+    if args.live_factor:
+        r.set_option(PT_OPT_LIVE_FACTOR, args.live_factor)
     if args.integrator == "nee":
         r.set_option(PT_OPT_INTEGRATOR, 1)
     if args.bsdf_probability != 1.0:
@@ -225,6 +228,8 @@ def main():
                          "launches_in_flight": st["extend_ms"] / st["extend_busy_ms"] if st["extend_busy_ms"] > 0 else 0.0,
                          "node_tests_per_ray": sc["node_tests"] / rays_c, "tri_tests_per_ray": sc["tri_tests"] / rays_c},
             "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "other": st["other_ms"]},
+            "device_bytes": st["device_bytes"],
+            "host_wait_ms": st["host_wait_ms"],
             "image_mean": float(img.mean()),
         }
         if not args.no_cpu_baseline and world == 1:

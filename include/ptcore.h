@@ -186,9 +186,11 @@ enum {
                                            direction per non-specular vertex tested with a shadow ray, the path continued
                                            by BSDF sampling, balance heuristic between the two; BSDF_SAMPLE_PROBABILITY
                                            is not used */
-    PT_OPT_TAIL_BELOW = 9               /* once a bounce is expected to carry fewer rays than this, one launch finishes the
-                                           batch instead of per-bounce launches; 0 = never (default:
-                                           measured no faster on the benchmark scenes) */
+    PT_OPT_TAIL_BELOW = 9,              /* accepted and ignored (it selected a launch that no longer exists) */
+    PT_OPT_LIVE_FACTOR = 13             /* rolling schedule: rays in flight a pipe has room for, as a multiple of the paths
+                                           started per launch (at least 2, at most max_depth; default 4).  A batch starts
+                                           only when its paths fit beside the rays in flight, so a scene whose paths live
+                                           longer than this allows for renders correctly, with batches starting less often */
 };
 
 typedef struct pt_context pt_context;

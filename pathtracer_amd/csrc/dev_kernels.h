@@ -96,13 +96,29 @@ __device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint3
     d = pixel_center - ray_center;
 }
 
-// The paths that start with a launch ("fresh" paths: the `n_new` paths in slots new_base ..) are on their camera
-// ray, which is never stored: whoever needs it computes it again from the path's pixel and stratum, together
-// with what else a path carries at that point (draws consumed so far, full depth, throughput 1).
+// A step's work list: the rays of the ray queue of its parity (`queued` positions, padding included), then the
+// paths that start with the step ("fresh" paths: the `n_new` paths in slots new_base ..).  A fresh path is on its
+// camera ray, which is never stored: whoever needs it computes it again from the path's pixel and stratum,
+// together with what else a path carries at that point (draws consumed so far, full depth, throughput 1).
 struct FreshPaths {
     uint32_t new_base, n_new;
-    __device__ __forceinline__ bool holds(uint32_t slot) const { return slot - new_base < n_new; }
 };
+struct WorkList {
+    uint32_t parity, queued;
+    FreshPaths fp;
+    __device__ __forceinline__ bool fresh(uint32_t pos) const { return pos >= queued; }
+    __device__ __forceinline__ uint32_t n_pieces() const { return queued / 64u + (fp.n_new + 63u) / 64u; }
+    // the path at a position; QUEUE_EMPTY for padding and past the end
+    __device__ __forceinline__ uint32_t slot(const PathState &ps, uint32_t pos) const {
+        if (pos < queued) return ps.ray_queue[parity][pos];
+        return pos - queued < fp.n_new ? fp.new_base + (pos - queued) : QUEUE_EMPTY;
+    }
+};
+__device__ __forceinline__ WorkList work_list(const PathState &ps, uint32_t bounce, FreshPaths fp) {
+    const uint32_t parity = bounce & 1u;
+    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
+    return WorkList{parity, n_chunks * QUEUE_CHUNK, fp};
+}
 __device__ __forceinline__ void fresh_path(const DevCamera &cam, const PathState &ps, uint32_t slot, f3 &o, f3 &d, uint32_t &draws, float &time) {
     uint64_t seed_mixed;
     uint32_t pixel, stratum;
@@ -113,30 +129,24 @@ __device__ __forceinline__ void fresh_path(const DevCamera &cam, const PathState
     draws = rng.counter;
     time = ps.moving ? path_time(rng.key) : 0.0f;
 }
-// Origin and direction of the ray a path is on.
-__device__ __forceinline__ void path_ray(const DevCamera &cam, const PathState &ps, uint32_t slot, bool fresh, f3 &o, f3 &d) {
-    if (fresh) {
+// Origin and direction of the ray at a position of the work list (which holds a path: not padding).
+__device__ __forceinline__ void path_ray(const DevCamera &cam, const PathState &ps, const WorkList &wl, uint32_t pos, f3 &o, f3 &d) {
+    if (wl.fresh(pos)) {
         uint32_t draws;
         float time;
-        fresh_path(cam, ps, slot, o, d, draws, time);
+        fresh_path(cam, ps, wl.fp.new_base + (pos - wl.queued), o, d, draws, time);
     } else {
-        const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+        const float4 ro = ps.ray_o[wl.parity][pos], rd = ps.ray_d[wl.parity][pos];
         o = mk3(ro.x, ro.y, ro.z);
         d = mk3(rd.x, rd.y, rd.z);
     }
 }
-// Entry i of a launch's work: the entries of the ray queue first (`queued` of them, padding included), then the
-// fresh paths.  False for padding and past the end.
-__device__ __forceinline__ bool work_entry(const uint32_t *queue, uint32_t queued, const FreshPaths &fp, uint32_t i, uint32_t &slot, bool &fresh) {
-    fresh = i >= queued;
-    if (!fresh) {
-        slot = queue[i];
-        return slot != QUEUE_EMPTY;
-    }
-    slot = fp.new_base + (i - queued);
-    return i - queued < fp.n_new;
+// First launch of a step: the batch that starts with it (if any) gets its region, and the count of the rays the
+// step's shading queues for the next step starts at zero.
+__global__ void k_tick_begin(RegionParams *regions, uint32_t region, RegionParams rp, uint32_t set_region, uint32_t *next_rays) {
+    if (set_region) regions[region] = rp;
+    if (next_rays) *next_rays = 0u;
 }
-__global__ void k_set_region(RegionParams *regions, uint32_t region, RegionParams rp) { regions[region] = rp; }
 
 // Rays only (pt_generate_rays).
 __global__ __launch_bounds__(BLOCK) void k_raygen_only(DevCamera cam, BatchParams bp, float *rays) {
@@ -156,12 +166,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // After the closest hit is known: missed paths and paths that hit a primitive without
-// material finish here (src/camera.rs:371, :277-283); the others are appended to the queue
-// of their material type.  Every lane of the wave must call this (inactive lanes with
+// material finish here (src/camera.rs:371, :277-283); the others are appended (by their position in the work
+// list) to the queue of their material type.  Every lane of the wave must call this (inactive lanes with
 // active == false), after shade_push_init() and before shade_push_close().
-// fresh: the path is on its camera ray (throughput 1, nothing stored for it yet).
-__device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, uint32_t parity, f3 background, bool active,
-                                         uint32_t slot, uint32_t code, uint32_t prim, bool fresh) {
+__device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, const WorkList &wl, f3 background, bool active, uint32_t pos, uint32_t code,
+                                         uint32_t prim) {
     uint32_t qslot = 0xFFu;
     if (active) {
         int32_t mat = -1;
@@ -173,7 +182,8 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
         // may still scatter on its way out, and shade_vertex<PTD_MAT_MEDIUM> decides (medium_queue is 0xFF otherwise)
         qslot = mat >= 0 ? sc.mat_queue[mat] : sc.medium_queue;
         if (qslot == 0xFFu) {
-            const float4 b = fresh ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ps.beta[slot];
+            const uint32_t slot = wl.slot(ps, pos);
+            const float4 b = wl.fresh(pos) ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : ps.beta[wl.parity][pos];
             if (!ps.nee) {
                 const f3 l = (code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
                 ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
@@ -193,7 +203,7 @@ __device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps
         WavePush w;
         w.chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[0]);
         w.fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)state[1]);
-        wave_push(w, mine, slot, ps.shade_queue[q], &ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE], ps.max_chunks, ps.queue_overflow);
+        wave_push(w, mine, pos, ps.shade_queue[q], &ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + wl.parity) * CTL_STRIDE], ps.max_chunks, ps.queue_overflow);
         if (lane_id() == 0u) {
             state[0] = w.chunk;
             state[1] = w.fill;
@@ -228,36 +238,52 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
     }
 }
 
-// Closest hit among the world's triangles, spheres and quads for every ray of the current
-// queue and every fresh path (first three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
+// Closest hit among the world's triangles, spheres and quads for every entry of the step's work list (first
+// three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
+// A scene with moving spheres (pts_moving_sphere) tests them last, where they are at the path's time.
+__device__ __forceinline__ float path_time_at(const DevCamera &cam, const PathState &ps, const WorkList &wl, uint32_t pos) {
+    if (!wl.fresh(pos)) return ps.beta[wl.parity][pos].w;
+    f3 o, d;
+    uint32_t draws;
+    float time;
+    fresh_path(cam, ps, wl.fp.new_base + (pos - wl.queued), o, d, draws, time);
+    return time;
+}
+__device__ __forceinline__ void hit_moving_spheres(const DevScene &sc, float time, TravRay &r, HitState &h, TravCounters &tc) {
+    for (uint32_t k = 0; k < sc.n_moving; k++) {
+        const uint32_t g = sc.n_static_spheres + k;
+        const float4 sp = sc.spheres[g], dl = sc.moving_delta[k];
+        const f3 c = mk3(sp.x, sp.y, sp.z) + time * mk3(dl.x, dl.y, dl.z);
+        tc.spheres++;
+        hit_sphere(make_float4(c.x, c.y, c.z, sp.w), g, r, h, 0u);
+    }
+}
 template <bool COUNT, bool CLASSIFY>
 __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
-    extend_prologue(ps, bounce, n_chunks, fp.n_new, stats);
+    const WorkList wl = work_list(ps, bounce, fp);
+    extend_prologue(ps, bounce, wl.queued, fp.n_new, stats);
     if (CLASSIFY) shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
-    const uint32_t *queue = ps.ray_queue[parity];
-    const uint32_t queued = n_chunks * QUEUE_CHUNK, n_pieces = queued / 64u + (fp.n_new + 63u) / 64u;
+    const uint32_t n_pieces = wl.n_pieces();
     for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
-        uint32_t slot;
-        bool fresh;
-        const bool active = work_entry(queue, queued, fp, piece * 64u + lane_id(), slot, fresh);
+        const uint32_t pos = piece * 64u + lane_id();
+        const bool active = wl.slot(ps, pos) != QUEUE_EMPTY;
         HitState h;
         h.code = PTD_HIT_MISS;
         h.prim = 0;
         if (active) {
             f3 o, d;
-            path_ray(cam, ps, slot, fresh, o, d);
+            path_ray(cam, ps, wl, pos, o, d);
             TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
             hit_world_prims(sc, r, h, st, tc);
-            ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-            ps.hit2[slot] = h.code;
+            if (CLASSIFY && sc.n_moving != 0u) hit_moving_spheres(sc, path_time_at(cam, ps, wl, pos), r, h, tc);
+            ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+            ps.hit2[pos] = h.code;
         }
-        if (CLASSIFY) classify(sc, ps, parity, background, active, slot, h.code, h.prim, fresh);
+        if (CLASSIFY) classify(sc, ps, wl, background, active, pos, h.code, h.prim);
     }
     if (CLASSIFY) shade_push_close(ps);
     flush_counters(COUNT, tc, stats);
@@ -272,117 +298,106 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, DevCamera cam, Pa
 #define PT_WALK_WAVES 5
 #endif
 #define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
-// The work is the current ray queue followed by the fresh paths (no queue entries exist for those).
 // MOVING: the scene has moving spheres (pts_moving_sphere): a finished ray is tested against them, where
 // they are at its path's time, before it is classified.
 template <bool INSTANCES, bool MOVING>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp,
                                                                       DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
-    extend_prologue(ps, bounce, n_chunks, fp.n_new, stats);
-    const uint32_t queued = n_chunks * QUEUE_CHUNK;
-    const uint32_t n_pieces = queued / 64u + (fp.n_new + 63u) / 64u;
+    const WorkList wl = work_list(ps, bounce, fp);
+    extend_prologue(ps, bounce, wl.queued, fp.n_new, stats);
+    const uint32_t n_pieces = wl.n_pieces();
     if (n_pieces == 0u) return;
     shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
-    const uint32_t *queue = ps.ray_queue[parity];
+    // a lane's ray is named by its position in the work list
     walk_world<INSTANCES>(
-        sc, n_pieces, &ps.ctl[(CTL_RAY_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
-        [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            bool fresh;
-            if (!work_entry(queue, queued, fp, i, slot, fresh)) return false;
+        sc, n_pieces, &ps.ctl[(CTL_RAY_CURSOR + wl.parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+        [&](uint32_t i, uint32_t &pos, TravRay &r) {
+            if (wl.slot(ps, i) == QUEUE_EMPTY) return false;
+            pos = i;
             f3 o, d;
-            path_ray(cam, ps, slot, fresh, o, d);
+            path_ray(cam, ps, wl, pos, o, d);
             r = make_trav_ray(o, d, 0.001f, INFINITY);
             return true;
         },
-        [&](uint32_t slot, f3 &o, f3 &d) { path_ray(cam, ps, slot, fp.holds(slot), o, d); },
-        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
-            const bool fresh = fp.holds(slot);
+        [&](uint32_t pos, f3 &o, f3 &d) { path_ray(cam, ps, wl, pos, o, d); },
+        [&](bool done, uint32_t pos, const TravRay &r, const HitState &h) {
             if constexpr (MOVING) {
                 TravRay r2 = r;
                 HitState h2 = h;
                 if (done) {
-                    float time;
-                    if (fresh) {
-                        f3 o, d;
-                        uint32_t draws;
-                        fresh_path(cam, ps, slot, o, d, draws, time);
-                    } else {
-                        time = ps.beta[slot].w;
-                    }
-                    for (uint32_t k = 0; k < sc.n_moving; k++) {
-                        const uint32_t g = sc.n_static_spheres + k;
-                        const float4 sp = sc.spheres[g], dl = sc.moving_delta[k];
-                        const f3 c = mk3(sp.x, sp.y, sp.z) + time * mk3(dl.x, dl.y, dl.z);
-                        hit_sphere(make_float4(c.x, c.y, c.z, sp.w), g, r2, h2, 0u);
-                    }
-                    ps.hit[slot] = make_float4(r2.t_max, h2.u, h2.v, __uint_as_float(h2.prim));
-                    ps.hit2[slot] = h2.code;
+                    TravCounters tc{0, 0, 0, 0};
+                    hit_moving_spheres(sc, path_time_at(cam, ps, wl, pos), r2, h2, tc);
+                    ps.hit[pos] = make_float4(r2.t_max, h2.u, h2.v, __uint_as_float(h2.prim));
+                    ps.hit2[pos] = h2.code;
                 }
-                classify(sc, ps, parity, background, done, slot, h2.code, h2.prim, fresh);
+                classify(sc, ps, wl, background, done, pos, h2.code, h2.prim);
             } else {
                 if (done) {
-                    ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-                    ps.hit2[slot] = h.code;
+                    ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+                    ps.hit2[pos] = h.code;
                 }
-                classify(sc, ps, parity, background, done, slot, h.code, h.prim, fresh);
+                classify(sc, ps, wl, background, done, pos, h.code, h.prim);
             }
         });
     shade_push_close(ps);
 }
 
 // The instance buffer of the world (last line of PrimitiveBuffer::hit, src/objects.rs:195),
-// continuing from the hit and t_max the first kernel left; then classification.
+// continuing from the hit and t_max the first kernel left; then the moving spheres, if any, and classification.
 template <bool COUNT>
 __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
+    const WorkList wl = work_list(ps, bounce, fp);
     shade_push_init();
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
-    const uint32_t *queue = ps.ray_queue[parity];
-    const uint32_t queued = n_chunks * QUEUE_CHUNK, n_pieces = queued / 64u + (fp.n_new + 63u) / 64u;
+    const uint32_t n_pieces = wl.n_pieces();
     for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
-        uint32_t slot;
-        bool fresh;
-        const bool active = work_entry(queue, queued, fp, piece * 64u + lane_id(), slot, fresh);
+        const uint32_t pos = piece * 64u + lane_id();
+        const bool active = wl.slot(ps, pos) != QUEUE_EMPTY;
         HitState h;
         h.code = PTD_HIT_MISS;
         h.prim = 0;
         if (active) {
             f3 o, d;
-            path_ray(cam, ps, slot, fresh, o, d);
-            const float4 h4 = ps.hit[slot];
+            path_ray(cam, ps, wl, pos, o, d);
+            const float4 h4 = ps.hit[pos];
             h.u = h4.y;
             h.v = h4.z;
             h.prim = __float_as_uint(h4.w);
-            h.code = ps.hit2[slot];
+            h.code = ps.hit2[pos];
             TravRay r = make_trav_ray(o, d, 0.001f, h4.x);
             const uint32_t before = h.code;
             const float t_before = r.t_max;
             hit_world_insts(sc, r, h, st, tc);
+            if (sc.n_moving != 0u) hit_moving_spheres(sc, path_time_at(cam, ps, wl, pos), r, h, tc);
             if (h.code != before || r.t_max != t_before || h.prim != __float_as_uint(h4.w)) {
-                ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-                ps.hit2[slot] = h.code;
+                ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+                ps.hit2[pos] = h.code;
             }
         }
-        classify(sc, ps, parity, background, active, slot, h.code, h.prim, fresh);
+        classify(sc, ps, wl, background, active, pos, h.code, h.prim);
     }
     shade_push_close(ps);
     flush_counters(COUNT, tc, stats);
 }
 
+// What a vertex leaves behind: the path's next ray with what travels with it (alive), and with next-event
+// estimation possibly a shadow ray.
+struct VertexOut {
+    bool alive, shadow;
+    float4 ray_o, ray_d, beta;            // as PathState stores them
+    float4 shadow_o, shadow_d, shadow_c;  // origin, direction, factor on the emitter's radiance
+};
+
 // The surface part of shade_vertex below.
 template <int MT, bool NEE>
-__device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, bool &shadow,
+__device__ __forceinline__ void shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, VertexOut &out,
                                               f3 ro, f3 rd, float4 h4, float4 b4, uint32_t code, f3 beta, uint32_t depth, uint32_t rng_counter) {
     const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code, NEE ? 0.0f : b4.w);
     const DevMaterial m = sc.mats[s.material];
-    shadow = false;
     if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
         // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
         f3 e = mk3(0.0f, 0.0f, 0.0f);
@@ -423,9 +438,10 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
                     if (sp > 0.0f) {
                         const f3 f = mat_eval<MT>(sc, m, w_out, wl, s) * fabsf(wl.y);
                         const f3 c = cmul(beta, f) / (lp + sp);
-                        ps.hit[slot] = make_float4(ls.x, ls.y, ls.z, 0.0f);
-                        ps.shadow_c[slot] = make_float4(c.x, c.y, c.z, 0.0f);
-                        shadow = true;
+                        out.shadow_o = make_float4(s.p.x, s.p.y, s.p.z, 0.0f);
+                        out.shadow_d = make_float4(ls.x, ls.y, ls.z, 0.0f);
+                        out.shadow_c = make_float4(c.x, c.y, c.z, 0.0f);
+                        out.shadow = true;
                     }
                 }
             }
@@ -477,21 +493,18 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
                 // the next ray_color call returns zeros without tracing (camera.rs:271-273)
                 if constexpr (!NEE) ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
             } else {
-                ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
-                ps.ray_d[slot] = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
-                ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, NEE ? drawn_with : b4.w);  // w: the path's time unless NEE
-                return true;
+                out.ray_o = make_float4(s.p.x, s.p.y, s.p.z, __uint_as_float(rng.counter));
+                out.ray_d = make_float4(w_in_world.x, w_in_world.y, w_in_world.z, __uint_as_float(depth));
+                out.beta = make_float4(beta.x, beta.y, beta.z, NEE ? drawn_with : b4.w);  // w: the path's time unless NEE
+                out.alive = true;
             }
         }
-        if (NEE && shadow) ps.ray_o[slot] = make_float4(s.p.x, s.p.y, s.p.z, 0.0f);  // the shadow ray still starts here
     }
-    return false;
 }
 
 // One path vertex: the body of Camera::ray_color after the hit (src/camera.rs:286-369), in
-// multiplicative form, for the path in `slot` whose hit (ps.hit, ps.hit2) has a material of
-// type MT; `local` is its number within its batch.  Returns true when the path goes on: its
-// next ray is then in ps.ray_o / ps.ray_d.
+// multiplicative form, for the path `slot` at position `pos` of the step's work list, whose hit
+// (ps.hit, ps.hit2) has a material of type MT.  out.alive: the path goes on with out.ray_o / ray_d / beta.
 //
 // NEE selects the integrator that is not in the reference (PT_OPT_INTEGRATOR = 1): next-event
 // estimation with one light sample per vertex and the balance heuristic, at the vertices whose
@@ -501,34 +514,35 @@ __device__ __forceinline__ bool shade_surface(const DevScene &sc, const PathStat
 // reference's estimator converges to, and those vertices are handled exactly as the reference
 // does, with BSDF sampling alone).  At a vertex with light sampling a direction is drawn with
 // LightBuffer::sample; when its density lp is positive and finite and the BSDF sampler could
-// have produced it (sp > 0), shadow = true and the path leaves (direction, beta * f * |cos| /
-// (lp + sp)) in ps.hit / ps.shadow_c for the shadow-ray kernel.  The path itself continues by
+// have produced it (sp > 0), out.shadow is set and out.shadow_o / shadow_d / shadow_c hold the shadow ray and
+// beta * f * |cos| / (lp + sp) for the shadow-ray kernel.  The path itself continues by
 // BSDF sampling with the reference's roulette; an emitter found that way counts with weight
 // sp' / (sp' + lp'), and fully after the camera or a vertex without light sampling.  Radiance is
 // added to ps.contrib as it is found; paths that end without finding any add nothing.
 template <int MT, bool NEE, bool MEDIA = false>
-__device__ __forceinline__ bool shade_vertex(const DevScene &sc, const DevCamera &cam, const PathState &ps, const BatchParams &bp, uint32_t slot, bool fresh, bool &shadow) {
+__device__ __forceinline__ void shade_vertex(const DevScene &sc, const DevCamera &cam, const PathState &ps, const BatchParams &bp, const WorkList &wl, uint32_t pos,
+                                             uint32_t slot, VertexOut &out) {
     f3 ro, rd;
     float4 b4;
     uint32_t depth;        // the max_depth argument of this ray_color call, >= 1
     uint32_t rng_counter;  // draws the path has consumed so far
-    if (fresh) {  // the camera ray is not stored anywhere: src/camera.rs:207-210 with the path's own generator again
+    out.alive = out.shadow = false;
+    if (wl.fresh(pos)) {  // the camera ray is not stored anywhere: src/camera.rs:207-210 with the path's own generator again
         float time;
         fresh_path(cam, ps, slot, ro, rd, rng_counter, time);
         depth = cam.max_depth;
         b4 = make_float4(1.0f, 1.0f, 1.0f, time);
     } else {
-        const float4 ro4 = ps.ray_o[slot], rd4 = ps.ray_d[slot];
+        const float4 ro4 = ps.ray_o[wl.parity][pos], rd4 = ps.ray_d[wl.parity][pos];
         ro = mk3(ro4.x, ro4.y, ro4.z);
         rd = mk3(rd4.x, rd4.y, rd4.z);
         rng_counter = __float_as_uint(ro4.w);
         depth = __float_as_uint(rd4.w);
-        b4 = ps.beta[slot];
+        b4 = ps.beta[wl.parity][pos];
     }
-    const float4 h4 = ps.hit[slot];
-    const uint32_t code = ps.hit2[slot];
+    const float4 h4 = ps.hit[pos];
+    const uint32_t code = ps.hit2[pos];
     f3 beta = mk3(b4.x, b4.y, b4.z);
-    shadow = false;
     if constexpr (MT == PTD_MAT_MEDIUM || MEDIA) {
         // participating media (not in the reference): the ray may scatter before it reaches what it hit
         uint64_t seed_mixed;
@@ -547,27 +561,28 @@ __device__ __forceinline__ bool shade_vertex(const DevScene &sc, const DevCamera
             depth -= 1u;
             if (depth == 0u) {
                 ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
-                return false;
+                return;
             }
-            ps.ray_o[slot] = make_float4(p.x, p.y, p.z, __uint_as_float(rng.counter));
-            ps.ray_d[slot] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth));
-            ps.beta[slot] = make_float4(beta.x, beta.y, beta.z, b4.w);
-            return true;
+            out.ray_o = make_float4(p.x, p.y, p.z, __uint_as_float(rng.counter));
+            out.ray_d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth));
+            out.beta = make_float4(beta.x, beta.y, beta.z, b4.w);
+            out.alive = true;
+            return;
         }
         rng_counter = rng.counter;
         if constexpr (MT == PTD_MAT_MEDIUM) {  // nothing to shade: src/camera.rs:371, :277-283
             const f3 l = missed ? bp.background : mk3(0.0f, 0.0f, 0.0f);
             ps.contrib[slot] = make_float4(beta.x * l.x, beta.y * l.y, beta.z * l.z, 0.0f);
-            return false;
+            return;
         }
     }
-    if constexpr (MT == PTD_MAT_MEDIUM) return false;
-    else return shade_surface<MT, NEE>(sc, ps, bp, slot, shadow, ro, rd, h4, b4, code, beta, depth, rng_counter);
+    if constexpr (MT != PTD_MAT_MEDIUM) shade_surface<MT, NEE>(sc, ps, bp, slot, out, ro, rd, h4, b4, code, beta, depth, rng_counter);
 }
 
-// shade_vertex for every path in the queue of material type MT; survivors go to the next ray queue.
+// shade_vertex for every entry of the queue of material type MT; survivors go to the next ray queue, their state
+// to the same position of the arrays that run beside it.
 // The queue may mix batches (each at a different bounce): `bp` holds what they have in common (sampling
-// probability, background), the rest comes from the path's region; `fp` names the paths on their camera ray.
+// probability, background), the rest comes from the path's region.
 // MODE: 0 = the reference's estimator, 1 = next-event estimation, 2 = the reference's estimator in a scene with
 // participating media.
 template <int MT, int MODE>
@@ -575,35 +590,51 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevCamera cam, Pat
     constexpr bool NEE = MODE == 1, MEDIA = MODE == 2;
     // a path ends at an emitter (src/camera.rs:288-290), unless a medium scatters it on its way there
     constexpr bool CONTINUES = MT != PTS_MAT_DIFFUSE_LIGHT || MEDIA;
-    const uint32_t parity = bounce & 1u;
+    const WorkList wl = work_list(ps, bounce, fp);
+    const uint32_t parity = wl.parity;
     const uint32_t n_chunks = min(ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + parity) * CTL_STRIDE], ps.max_chunks);
     if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_SHADE_CHUNKS + 2u * q + (parity ^ 1u)) * CTL_STRIDE] = 0u;
     const uint32_t *queue = ps.shade_queue[q];
-    WavePush out, shadows;
-    out.init();
+    WavePush next, shadows;
+    next.init();
     shadows.init();
-    uint32_t survivors = 0u;  // rays this launch starts: next-bounce rays and shadow rays
+    uint32_t survivors = 0u, shadow_rays = 0u;
     const PieceWalk pw = piece_walk(n_chunks);
     for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        bool alive = false, shadow = false;
-        if (slot != QUEUE_EMPTY) alive = shade_vertex<MT, NEE, MEDIA>(sc, cam, ps, bp, slot, fp.holds(slot), shadow);
+        const uint32_t pos = queue[(size_t)piece * 64u + lane_id()];
+        VertexOut v;
+        v.alive = v.shadow = false;
+        uint32_t slot = QUEUE_EMPTY;
+        if (pos != QUEUE_EMPTY) {
+            slot = wl.slot(ps, pos);
+            shade_vertex<MT, NEE, MEDIA>(sc, cam, ps, bp, wl, pos, slot, v);
+        }
         if constexpr (CONTINUES) {
-            survivors += (uint32_t)__popcll(__ballot(alive));
-            wave_push(out, alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE], ps.max_ray_chunks, ps.queue_overflow);
-            if constexpr (NEE) {
-                survivors += (uint32_t)__popcll(__ballot(shadow));
-                wave_push(shadows, shadow, slot, ps.shadow_queue, &ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks, ps.queue_overflow);
+            survivors += (uint32_t)__popcll(__ballot(v.alive));
+            const uint32_t to = wave_push(next, v.alive, slot, ps.ray_queue[parity ^ 1u], &ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE], ps.max_ray_chunks,
+                                          ps.queue_overflow);
+            if (to != QUEUE_EMPTY) {
+                ps.ray_o[parity ^ 1u][to] = v.ray_o;
+                ps.ray_d[parity ^ 1u][to] = v.ray_d;
+                ps.beta[parity ^ 1u][to] = v.beta;
+            }
+        }
+        if constexpr (NEE) {
+            shadow_rays += (uint32_t)__popcll(__ballot(v.shadow));
+            const uint32_t to = wave_push(shadows, v.shadow, slot, ps.shadow_queue, &ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks, ps.queue_overflow);
+            if (to != QUEUE_EMPTY) {
+                ps.shadow_o[to] = v.shadow_o;
+                ps.shadow_d[to] = v.shadow_d;
+                ps.shadow_c[to] = v.shadow_c;
             }
         }
     }
-    if constexpr (CONTINUES) {
-        wave_push_close(out, ps.ray_queue[parity ^ 1u]);
-        if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
-        if (survivors && lane_id() == 0u) {
-            atomicAdd(&stats->rays_total, (unsigned long long)survivors);
-            if (ps.bounce_rays && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
-        }
+    if constexpr (CONTINUES) wave_push_close(next, ps.ray_queue[parity ^ 1u]);
+    if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
+    if ((survivors | shadow_rays) && lane_id() == 0u) {
+        atomicAdd(&stats->rays_total, (unsigned long long)(survivors + shadow_rays));
+        if (survivors && ps.next_rays) atomicAdd(ps.next_rays, survivors);
+        if (survivors && ps.bounce_rays && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
     }
 }
 
@@ -621,92 +652,35 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_walk(DevScene sc, PathState ps
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     const uint32_t *queue = ps.shadow_queue;
+    // a lane's ray is named by its position in the shadow queue
     walk_world<INSTANCES>(
         sc, n_chunks * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_SHADOW_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
-        [&](uint32_t i, uint32_t &slot, TravRay &r) {
-            slot = queue[i];
-            if (slot == QUEUE_EMPTY) return false;
-            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
+        [&](uint32_t i, uint32_t &pos, TravRay &r) {
+            if (queue[i] == QUEUE_EMPTY) return false;
+            pos = i;
+            const float4 ro = ps.shadow_o[i], rd = ps.shadow_d[i];
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
             return true;
         },
-        [&](uint32_t slot, f3 &o, f3 &d) {
-            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
+        [&](uint32_t pos, f3 &o, f3 &d) {
+            const float4 ro = ps.shadow_o[pos], rd = ps.shadow_d[pos];
             o = mk3(ro.x, ro.y, ro.z);
             d = mk3(rd.x, rd.y, rd.z);
         },
-        [&](bool done, uint32_t slot, const TravRay &r, const HitState &h) {
+        [&](bool done, uint32_t pos, const TravRay &r, const HitState &h) {
             if (!done || h.code == PTD_HIT_MISS) return;
             const uint32_t type = h.code & 3u;
             const int32_t mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
             if (mat < 0 || sc.mats[mat].type != PTS_MAT_DIFFUSE_LIGHT) return;
-            const float4 ro = ps.ray_o[slot], rd = ps.hit[slot];
+            const float4 ro = ps.shadow_o[pos], rd = ps.shadow_d[pos];
             const Surf s = make_surf(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), r.t_max, h.u, h.v, h.prim, h.code);
             if (!s.front_face) return;
             const f3 e = tex_value(sc, sc.mats[mat].texture, s.u, s.v, s.p);
-            const float4 f = ps.shadow_c[slot], c = ps.contrib[slot];
+            const uint32_t slot = queue[pos];
+            const float4 f = ps.shadow_c[pos], c = ps.contrib[slot];
             const f3 add = cmul(mk3(f.x, f.y, f.z), e);
             ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
         });
-}
-
-// Everything that is left of a batch from bounce `bounce` on, in one launch: each lane takes a
-// path of the ray queue and alternates closest hit (the reference-order loop) and shade_vertex
-// until the path ends.  Used where a batch has thinned to a few thousand paths: per-bounce
-// launches then cost more in launch latency than the work they carry, and this also covers
-// however many bounces remain without the host having to know.  The functions are the ones the
-// per-bounce kernels call, so every path gets the same arithmetic.
-__global__ __launch_bounds__(BLOCK) void k_tail(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, f3 background, DevStats *stats) {
-    const uint32_t parity = bounce & 1u;
-    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
-    LaneStack st;
-    st.init(ps.overflow, ps.overflow_stride);
-    TravCounters tc{0, 0, 0, 0};
-    const uint32_t *queue = ps.ray_queue[parity];
-    const bool insts = sc.world.insts.prim_count != 0u;
-    uint32_t traced = 0u;  // rays beyond the ones the queue held (those are already counted)
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
-        const uint32_t slot = queue[(size_t)piece * 64u + lane_id()];
-        if (slot == QUEUE_EMPTY) continue;
-        for (;;) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            HitState h;
-            hit_world_prims(sc, r, h, st, tc);
-            if (insts) hit_world_insts(sc, r, h, st, tc);
-            int32_t mat = -1;
-            if (h.code != PTD_HIT_MISS) {
-                const uint32_t type = h.code & 3u;
-                mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
-            }
-            if (mat < 0) {  // src/camera.rs:371, :277-283
-                const float4 b = ps.beta[slot];
-                const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
-                ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
-                break;
-            }
-            ps.hit[slot] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-            ps.hit2[slot] = h.code;
-            bool alive = false, shadow;
-            switch (sc.mats[mat].type) {
-                case PTS_MAT_LAMBERTIAN: alive = shade_vertex<PTS_MAT_LAMBERTIAN, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_METAL: alive = shade_vertex<PTS_MAT_METAL, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DIELECTRIC: alive = shade_vertex<PTS_MAT_DIELECTRIC, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DIFFUSE_LIGHT: alive = shade_vertex<PTS_MAT_DIFFUSE_LIGHT, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DISNEY: alive = shade_vertex<PTS_MAT_DISNEY, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DISNEY_DIFFUSE: alive = shade_vertex<PTS_MAT_DISNEY_DIFFUSE, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DISNEY_METAL: alive = shade_vertex<PTS_MAT_DISNEY_METAL, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DISNEY_GLASS: alive = shade_vertex<PTS_MAT_DISNEY_GLASS, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DISNEY_CLEARCOAT: alive = shade_vertex<PTS_MAT_DISNEY_CLEARCOAT, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                case PTS_MAT_DISNEY_SHEEN: alive = shade_vertex<PTS_MAT_DISNEY_SHEEN, false>(sc, cam, ps, bp, slot, false, shadow); break;
-                default: break;
-            }
-            if (!alive) break;
-            traced++;
-        }
-    }
-    if (traced) atomicAdd(&stats->rays_total, (unsigned long long)traced);
 }
 
 // `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).  The
@@ -781,8 +755,8 @@ __global__ __launch_bounds__(BLOCK) void k_tonemap(const float *accum, uint8_t *
 __global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathState ps, uint32_t n) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         const float *r = rays + 8 * (size_t)i;
-        ps.ray_o[i] = make_float4(r[0], r[1], r[2], r[6]);
-        ps.ray_d[i] = make_float4(r[3], r[4], r[5], r[7]);
+        ps.ray_o[0][i] = make_float4(r[0], r[1], r[2], r[6]);
+        ps.ray_d[0][i] = make_float4(r[3], r[4], r[5], r[7]);
         ps.ray_queue[0][i] = i;
     }
     const uint32_t n_chunks = (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK;
@@ -801,7 +775,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i];
+        const float4 ro = ps.ray_o[0][i], rd = ps.ray_d[0][i];
         TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
         HitState h;
         hit_world_prims(sc, r, h, st, tc);
@@ -818,12 +792,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = ps.ray_queue[0][i];
             if (slot == QUEUE_EMPTY) return false;
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            const float4 ro = ps.ray_o[0][slot], rd = ps.ray_d[0][slot];
             r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
             return true;
         },
         [&](uint32_t slot, f3 &o, f3 &d) {
-            const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+            const float4 ro = ps.ray_o[0][slot], rd = ps.ray_d[0][slot];
             o = mk3(ro.x, ro.y, ro.z);
             d = mk3(rd.x, rd.y, rd.z);
         },
@@ -839,7 +813,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps,
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i], h4 = ps.hit[i];
+        const float4 ro = ps.ray_o[0][i], rd = ps.ray_d[0][i], h4 = ps.hit[i];
         HitState h;
         h.u = h4.y;
         h.v = h4.z;
@@ -855,7 +829,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_inst(DevScene sc, PathState ps,
 // scene left: the last line of the renderer's closest-hit step, for caller-supplied rays.
 __global__ __launch_bounds__(BLOCK) void k_trace_moving(DevScene sc, PathState ps, uint32_t n, const float *times) {
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const float4 ro = ps.ray_o[i], rd = ps.ray_d[i], h4 = ps.hit[i];
+        const float4 ro = ps.ray_o[0][i], rd = ps.ray_d[0][i], h4 = ps.hit[i];
         HitState h;
         h.u = h4.y;
         h.v = h4.z;

@@ -27,10 +27,12 @@ __device__ __forceinline__ void wave_push_close(const WavePush &w, uint32_t *ent
 // fills it); should a queue still run out of its `max_chunks` chunks, the push is dropped and
 // counted in *overflowed, which the next synchronising call reports as an error, instead of
 // writing past the end of the array.
-__device__ __forceinline__ void wave_push(WavePush &w, bool want, uint32_t id, uint32_t *entries, uint32_t *n_chunks, uint32_t max_chunks,
-                                          unsigned long long *overflowed) {
+// Returns the position of the lane's entry in the queue (QUEUE_EMPTY for lanes that push nothing, or whose push
+// was dropped): arrays that run parallel to a queue are indexed by it.
+__device__ __forceinline__ uint32_t wave_push(WavePush &w, bool want, uint32_t id, uint32_t *entries, uint32_t *n_chunks, uint32_t max_chunks,
+                                              unsigned long long *overflowed) {
     const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
+    if (mask == 0ull) return QUEUE_EMPTY;
     const uint32_t k = (uint32_t)__popcll(mask);
     if (w.chunk == QUEUE_EMPTY || w.fill + k > QUEUE_CHUNK) {
         wave_push_close(w, entries);
@@ -42,12 +44,14 @@ __device__ __forceinline__ void wave_push(WavePush &w, bool want, uint32_t id, u
             // consumers walk min(chunk count, max_chunks) chunks, so the count may stay above the capacity
             if (lane_id() == 0u) atomicAdd(overflowed, (unsigned long long)k);
             w.chunk = QUEUE_EMPTY;
-            return;
+            return QUEUE_EMPTY;
         }
     }
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (want) entries[(size_t)w.chunk * QUEUE_CHUNK + w.fill + rank] = id;
+    const uint32_t pos = w.chunk * QUEUE_CHUNK + w.fill + rank;
+    if (want) entries[pos] = id;
     w.fill += k;
+    return want ? pos : QUEUE_EMPTY;
 }
 
 // Identity of the calling wave in the launch, and the number of waves in it.

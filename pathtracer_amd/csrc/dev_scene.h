@@ -130,18 +130,27 @@ struct RegionParams {  // 32 B
     uint32_t unused[4];
 };
 
-// Per-path state, indexed by slot = pixel * strata_in_batch + (stratum - batch_first_stratum).
+// Path state.  A path is named by its slot: first slot of its batch's region + pixel * strata_in_batch + (stratum -
+// batch_first_stratum); only its radiance is stored by slot.  What a path carries from one vertex to the next
+// (ray, draw counter, depth, throughput) travels with its ray: it is stored by the POSITION of the ray in the ray
+// queue of the step that traces it, two sets used in ping-pong by step parity, so the arrays are as long as the
+// largest number of rays in flight, not as the number of paths started, and a step reads them nearly in order.
+// Paths on their camera ray have no stored state at all (dev_kernels.h, FreshPaths).  The results of a step's
+// closest-hit search are stored by position in the step's work list: the ray queue's positions first, then the
+// step's fresh paths.
 struct PathState {
-    float4 *ray_o;    // origin.xyz, rng draw counter (bits)
-    float4 *ray_d;    // direction.xyz, remaining depth (bits)
-    float4 *beta;     // path throughput so far; w: density with which the current ray was drawn (next-event estimation only)
-    float4 *hit;      // t, u, v, global primitive index (bits)
+    float4 *ray_o[2];   // [parity][position]: origin.xyz, rng draw counter (bits)
+    float4 *ray_d[2];   // direction.xyz, remaining depth (bits)
+    float4 *beta[2];    // path throughput so far; w: density with which the current ray was drawn (next-event
+                        // estimation), else the path's time (scenes with moving spheres)
+    uint32_t *ray_queue[2];             // [parity][position]: slot of the path; max_ray_chunks * QUEUE_CHUNK entries each
+    float4 *hit;      // [work-list position]: t, u, v, global primitive index (bits)
     uint32_t *hit2;   // type | (instance+1) << 2, or PTD_HIT_MISS
-    float4 *contrib;  // radiance of the finished path (xyz)
-    uint32_t *ray_queue[2];             // max_chunks * QUEUE_CHUNK entries each
-    uint32_t *shade_queue[MAX_QUEUES];  // likewise; only the queues of material types in use exist
+    float4 *contrib;  // [slot]: radiance of the finished path (xyz); zero between uses
+    uint32_t *shade_queue[MAX_QUEUES];  // work-list positions by material type; only the queues of types in use exist
     uint32_t *ctl;                      // CTL_WORDS control words
-    uint32_t *bounce_rays;              // [BOUNCE_PROFILE_LEN] rays traced at each bounce of the batch ([0] unused)
+    uint32_t *bounce_rays;              // [BOUNCE_PROFILE_LEN] rays traced at each bounce of the batch ([0] unused); may be null
+    uint32_t *next_rays;                // rays the shading of this step has queued for the next one so far; may be null
     uint32_t max_chunks;      // capacity of each material queue, in chunks
     uint32_t max_ray_chunks;  // capacity of each ray queue and of the shadow-ray queue (several launches fill them)
     unsigned long long *queue_overflow;  // entries dropped because a queue was full (never, unless the sizing is wrong)
@@ -151,15 +160,14 @@ struct PathState {
     uint32_t n_slots;
     int refill_below;          // a traversing wave with fewer busy lanes than this goes back for more rays
     int leaf_batch;            // lanes that must be waiting at a leaf before the wave runs a primitive test
-    RegionParams *regions;     // [slots / region_cap] batches the regions hold (only where batches share launches)
+    RegionParams *regions;     // [slots / region_cap] the batches the regions hold
     uint32_t region_cap;       // slots per region
-    // next-event estimation (PT_OPT_INTEGRATOR = 1): a vertex may leave a shadow ray behind, from the new
-    // ray origin (ray_o) along hit.xyz (hit is free between shading and the next closest-hit step); if it
-    // reaches an emitter, shadow_c times the emitted radiance is added to the path's contrib
+    // next-event estimation (PT_OPT_INTEGRATOR = 1): a vertex may leave a shadow ray behind; if it reaches an
+    // emitter, shadow_c times the emitted radiance is added to the path's contrib
     uint32_t nee;
-    uint32_t moving;  // the scene has moving spheres: beta.w holds the path's time instead
-    uint32_t *shadow_queue;
-    float4 *shadow_c;
+    uint32_t moving;  // the scene has moving spheres: beta.w holds the path's time
+    uint32_t *shadow_queue;                    // slot of the path each shadow ray belongs to
+    float4 *shadow_o, *shadow_d, *shadow_c;    // [position in the shadow queue]: origin, direction, factor
 };
 
 }  // namespace ptd

@@ -56,7 +56,7 @@ struct pt_context {
     int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
     bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
     uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
-    int tail_below = 0;  // rays under which the rest of a batch goes to one launch (0: never)
+    double live_factor = 4.0;  // PT_OPT_LIVE_FACTOR
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -104,7 +104,17 @@ struct pt_context {
         PathState ps{};
         std::vector<std::pair<void *, size_t>> allocs;
         uint32_t n_regions = 0, cap = 0;
+        uint64_t n_live = 0;  // rays in flight the arrays have room for
         uint64_t tick = 0;
+        // Admission: a batch starts only if its paths and the rays already in flight fit n_live.  The shading of
+        // tick t counts the rays it queues for tick t + 1 (tick_rays[t % ROLL_RING], copied to host_tick_rays when
+        // the tick is through); ticks [0, counted) are known to be through, known_rays = what the last of them
+        // queued, and ring_new[] holds the paths started by the ticks after that.
+        uint32_t *tick_rays = nullptr;
+        uint32_t *host_tick_rays = nullptr;  // pinned
+        uint32_t ring_new[ROLL_RING] = {};
+        uint64_t counted = 0;
+        uint32_t known_rays = 0;
         std::deque<Due> due;
         hipEvent_t done[ROLL_RING] = {}, accumulated[ROLL_RING] = {};
         hipEvent_t prof[ROLL_RING][4] = {};  // before raygen, before extend, after extend, after shading
@@ -203,6 +213,10 @@ static hipError_t scratch_lookup(int device);
 static void free_roll(pt_context *ctx, pt_context::Roll &r) {
     free_pool(ctx, r.allocs);
     r.n_regions = r.cap = 0;
+    r.n_live = 0;
+    r.tick_rays = nullptr;
+    r.counted = 0;
+    r.known_rays = 0;
     r.tick = 0;
     r.due.clear();
     for (bool &b : r.prof_pending) b = false;
@@ -210,6 +224,8 @@ static void free_roll(pt_context *ctx, pt_context::Roll &r) {
 static void destroy_pipes(pt_context *ctx) {
     for (auto &r : ctx->rolls) {
         free_roll(ctx, r);
+        if (r.host_tick_rays) (void)hipHostFree(r.host_tick_rays);
+        r.host_tick_rays = nullptr;
         for (int i = 0; i < pt_context::ROLL_RING; i++) {
             if (r.done[i]) (void)hipEventDestroy(r.done[i]);
             if (r.accumulated[i]) (void)hipEventDestroy(r.accumulated[i]);
@@ -352,6 +368,7 @@ int pt_create(int device, pt_context **out) {
         if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated[k], hipEventDisableTiming);
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc((void **)&ctx->pipes[i].host_chunks[k], BOUNCE_PROFILE_LEN * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->rolls[i].host_tick_rays, pt_context::ROLL_RING * sizeof(uint32_t), hipHostMallocDefault);
         for (int k = 0; k < pt_context::ROLL_RING && e == hipSuccess; k++) {
             e = hipEventCreateWithFlags(&ctx->rolls[i].done[k], hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->rolls[i].accumulated[k], hipEventDisableTiming);
@@ -445,9 +462,12 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "paths per launch out of range");
             ctx->roll_paths = (uint64_t)value;
             return PT_OK;
-        case PT_OPT_TAIL_BELOW:
+        case PT_OPT_TAIL_BELOW:  // kept for callers that set it: the launch it switched on is gone
             if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "tail threshold out of range");
-            ctx->tail_below = (int)value;
+            return PT_OK;
+        case PT_OPT_LIVE_FACTOR:
+            if (!(value >= 2.0 && value <= 1.0e6)) return fail(ctx, PT_ERR_INVALID, "live factor must be at least 2");
+            ctx->live_factor = value;
             return PT_OK;
         case PT_OPT_LEAF_BATCH:
             if (!(value >= 1.0 && value <= 64.0)) return fail(ctx, PT_ERR_INVALID, "leaf batch must be in [1,64]");
@@ -971,46 +991,67 @@ static void queue_capacity(const pt_context *ctx, uint64_t n_slots, uint64_t &ma
     max_ray_chunks = n_slots / (QUEUE_CHUNK - 63u) + (uint64_t)std::max<uint32_t>(1u, ctx->n_queues) * max_waves + 8u;
 }
 
+// Path state for `n_slots` paths of which at most `n_live` have a ray queued for one step and at most `n_fresh`
+// start with one step (dev_scene.h, PathState): radiance by slot, travelling state by ray-queue position, hits
+// and material queues by work-list position.
+static int alloc_path_state(pt_context *ctx, std::vector<std::pair<void *, size_t>> &pool, hipStream_t st, PathState &ps, uint64_t n_slots, uint64_t n_live,
+                            uint64_t n_fresh, uint32_t n_regions) {
+    int rc;
+    uint64_t unused, max_ray_chunks, max_chunks, max_shadow_chunks;
+    queue_capacity(ctx, n_live, unused, max_ray_chunks);
+    queue_capacity(ctx, n_live + n_fresh, max_chunks, max_shadow_chunks);
+    const uint64_t positions = max_ray_chunks * QUEUE_CHUNK;
+    if (positions + n_fresh >= (1ull << 32) || max_shadow_chunks * QUEUE_CHUNK >= (1ull << 32)) return fail(ctx, PT_ERR_INVALID, "too many rays in flight for 32-bit positions");
+    ps.max_chunks = (uint32_t)max_chunks;
+    ps.max_ray_chunks = (uint32_t)max_ray_chunks;
+    ps.queue_overflow = &ctx->stats->queue_overflow;
+    ps.n_queues = ctx->n_queues;
+    if ((rc = dev_alloc(ctx, pool, &ps.contrib, n_slots))) return rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = dev_alloc(ctx, pool, &ps.ray_o[k], positions))) return rc;
+        if ((rc = dev_alloc(ctx, pool, &ps.ray_d[k], positions))) return rc;
+        if ((rc = dev_alloc(ctx, pool, &ps.beta[k], positions))) return rc;
+        if ((rc = dev_alloc(ctx, pool, &ps.ray_queue[k], positions))) return rc;
+    }
+    if ((rc = dev_alloc(ctx, pool, &ps.hit, positions + n_fresh))) return rc;
+    if ((rc = dev_alloc(ctx, pool, &ps.hit2, positions + n_fresh))) return rc;
+    for (uint32_t q = 0; q < ctx->n_queues; q++)
+        if ((rc = dev_alloc(ctx, pool, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
+    if ((rc = dev_alloc(ctx, pool, &ps.ctl, (size_t)CTL_WORDS))) return rc;
+    if ((rc = dev_alloc(ctx, pool, &ps.regions, (size_t)n_regions))) return rc;
+    // radiance slots start at zero and are left at zero by whoever reads them (k_accumulate, pt_render_samples)
+    HIP_TRY(ctx, hipMemsetAsync(ps.contrib, 0, n_slots * sizeof(float4), st));
+    HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(ps.regions, 0, n_regions * sizeof(RegionParams), st));
+    ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
+    ps.nee = ctx->nee ? 1u : 0u;
+    if (ctx->nee) {  // at most one shadow ray per vertex, filled by every shading launch of a step
+        const uint64_t shadow_positions = max_shadow_chunks * QUEUE_CHUNK;
+        if ((rc = dev_alloc(ctx, pool, &ps.shadow_queue, shadow_positions))) return rc;
+        if ((rc = dev_alloc(ctx, pool, &ps.shadow_o, shadow_positions))) return rc;
+        if ((rc = dev_alloc(ctx, pool, &ps.shadow_d, shadow_positions))) return rc;
+        if ((rc = dev_alloc(ctx, pool, &ps.shadow_c, shadow_positions))) return rc;
+    }
+    // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
+    ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
+    const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
+    if ((rc = dev_alloc(ctx, pool, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
+    ps.refill_below = ctx->refill_below;
+    ps.leaf_batch = ctx->leaf_batch;
+    ps.n_slots = (uint32_t)n_slots;
+    return PT_OK;
+}
 static int ensure_paths(pt_context *ctx, pt_context::Pipe &pp, uint64_t n_slots) {
     if (n_slots <= pp.capacity) return PT_OK;
     (void)hipStreamSynchronize(pp.stream);
     free_pool(ctx, pp.allocs);
     pp.capacity = 0;
     PathState ps{};
-    int rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_o, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_d, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.beta, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.hit2, n_slots))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.contrib, n_slots))) return rc;
-    uint64_t max_chunks, max_ray_chunks;
-    queue_capacity(ctx, n_slots, max_chunks, max_ray_chunks);
-    ps.max_chunks = (uint32_t)max_chunks;
-    ps.max_ray_chunks = (uint32_t)max_ray_chunks;
-    ps.queue_overflow = &ctx->stats->queue_overflow;
-    ps.n_queues = ctx->n_queues;
-    for (int k = 0; k < 2; k++)
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.ray_queue[k], max_ray_chunks * QUEUE_CHUNK))) return rc;
-    for (uint32_t q = 0; q < ctx->n_queues; q++)
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
+    // one batch at a time: every path may be alive at every bounce, and all of them start with the first step
+    int rc = alloc_path_state(ctx, pp.allocs, pp.stream, ps, n_slots, n_slots, n_slots, 1u);
+    if (rc) return rc;
     if ((rc = dev_alloc(ctx, pp.allocs, &ps.bounce_rays, (size_t)BOUNCE_PROFILE_LEN))) return rc;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.regions, (size_t)1))) return rc;
-    // radiance slots start at zero and are left at zero by whoever reads them (k_accumulate, pt_render_samples)
-    HIP_TRY(ctx, hipMemsetAsync(ps.contrib, 0, n_slots * sizeof(float4), pp.stream));
-    ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
-    ps.nee = ctx->nee ? 1u : 0u;
-    if (ctx->nee) {
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_queue, max_ray_chunks * QUEUE_CHUNK))) return rc;
-        if ((rc = dev_alloc(ctx, pp.allocs, &ps.shadow_c, n_slots))) return rc;
-    }
-    // stack entries beyond the LDS part: one slab of (lanes in the widest launch) per level
-    ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
-    const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
-    if ((rc = dev_alloc(ctx, pp.allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
-    ps.refill_below = ctx->refill_below;
-    ps.leaf_batch = ctx->leaf_batch;
+    ps.next_rays = nullptr;
     pp.ps = ps;
     pp.capacity = n_slots;
     return PT_OK;
@@ -1151,7 +1192,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     rp.seed_mixed = bp.seed_mixed;
     rp.stratum_first = first;
     rp.n_strata = k;
-    hipLaunchKernelGGL(k_set_region, dim3(1), dim3(1), 0, st, ps.regions, 0u, rp);
+    hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(1), 0, st, ps.regions, 0u, rp, 1u, (uint32_t *)nullptr);
     size_t ev = 0;
     const bool prof = ctx->profile;
     if (prof) (void)hipEventRecord(get_event(pp, ev++), st);  // (the two events that used to bracket ray generation)
@@ -1163,17 +1204,6 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
         if (b == 0 || b >= ctx->bounce_profile.size() || ctx->bounce_profile[0] == 0u) return 0;
         return (uint64_t)((double)ctx->bounce_profile[b] * ((double)n_slots / (double)ctx->bounce_profile[0])) + 1u;
     };
-    // From the first bounce expected to carry fewer than tail_below rays, one launch finishes the batch.
-    uint32_t tail_from = depth;
-    if (ctx->tail_below > 0 && !ctx->counters && !ctx->nee && ctx->scene.n_media == 0 && ctx->scene.n_moving == 0)
-        for (uint32_t b = 1; b < depth; b++) {
-            const uint64_t e = expected(b);
-            if (e == 0) break;
-            if (e < (uint64_t)ctx->tail_below) {
-                tail_from = b;
-                break;
-            }
-        }
     uint32_t bounces = 0;
     for (uint32_t b = 0; b < depth; b++, bounces++) {
         // one lane per expected ray, twice that for slack (any size is correct: the kernels loop over their queues)
@@ -1182,15 +1212,6 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
             const int want = (int)std::min<uint64_t>((rays + BLOCK - 1) / BLOCK * 2u + 8u, 1u << 30);
             g_ext = std::min(grid, (want + 7) / 8 * 8);
             g_sh = std::min(grid_shade, (want + 7) / 8 * 8);
-        }
-        if (b == tail_from) {
-            hipLaunchKernelGGL(k_tail, dim3(g_ext), dim3(BLOCK), 0, st, ctx->scene, ctx->cam, ps, bp, b, ctx->cam.background, ctx->stats);
-            if (prof) {
-                (void)hipEventRecord(get_event(pp, ev++), st);
-                (void)hipEventRecord(get_event(pp, ev++), st);
-            }
-            bounces++;
-            break;
         }
         const FreshPaths fp{0u, b == 0u ? (uint32_t)n_slots : 0u};  // every path of the batch starts with its first step
         launch_extend(ctx, st, g_ext, ps, b, fp);
@@ -1205,59 +1226,40 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
 }
 
 // ---------------------------------------------------------------- rolling schedule
-// Slot arrays of n_regions * cap paths and queues for the case that all of them are alive.
-static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &r, uint32_t n_regions, uint32_t cap) {
-    if (r.n_regions == n_regions && r.cap == cap) return PT_OK;
+// Path state of a rolling pipe: radiance slots for n_regions batches of cap paths, and room for n_live rays in flight.
+static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &r, uint32_t n_regions, uint32_t cap, uint64_t n_live) {
+    if (r.n_regions == n_regions && r.cap == cap && r.n_live == n_live) return PT_OK;
     (void)hipStreamSynchronize(pp.stream);  // the caller has finished the batches under way
     free_roll(ctx, r);
     const uint64_t total = (uint64_t)n_regions * cap;
     PathState ps{};
-    int rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_o, total))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_d, total))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.beta, total))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.hit, total))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.hit2, total))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.contrib, total))) return rc;
-    uint64_t max_chunks, max_ray_chunks;
-    queue_capacity(ctx, total, max_chunks, max_ray_chunks);
-    ps.max_chunks = (uint32_t)max_chunks;
-    ps.max_ray_chunks = (uint32_t)max_ray_chunks;
-    ps.queue_overflow = &ctx->stats->queue_overflow;
-    ps.n_queues = ctx->n_queues;
-    for (int k = 0; k < 2; k++)
-        if ((rc = dev_alloc(ctx, r.allocs, &ps.ray_queue[k], max_ray_chunks * QUEUE_CHUNK))) return rc;
-    for (uint32_t q = 0; q < ctx->n_queues; q++)
-        if ((rc = dev_alloc(ctx, r.allocs, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.ctl, (size_t)CTL_WORDS))) return rc;
+    int rc = alloc_path_state(ctx, r.allocs, pp.stream, ps, total, n_live, cap, n_regions);
+    if (rc) return rc;
     ps.bounce_rays = nullptr;  // rays per bounce are only recorded where a batch has its launches to itself
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.regions, (size_t)n_regions))) return rc;
-    HIP_TRY(ctx, hipMemsetAsync(ps.contrib, 0, total * sizeof(float4), pp.stream));  // see ensure_paths
-    ps.moving = ctx->scene.n_moving != 0 ? 1u : 0u;
-    ps.nee = ctx->nee ? 1u : 0u;
-    if (ctx->nee) {
-        if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_queue, max_ray_chunks * QUEUE_CHUNK))) return rc;
-        if ((rc = dev_alloc(ctx, r.allocs, &ps.shadow_c, total))) return rc;
-    }
-    HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, CTL_WORDS * sizeof(uint32_t), pp.stream));
-    HIP_TRY(ctx, hipMemsetAsync(ps.regions, 0, n_regions * sizeof(RegionParams), pp.stream));
-    ps.overflow_stride = (uint32_t)grid_fixed(ctx, ~0ull >> 1) * BLOCK;
-    const uint32_t extra = ctx->stack_need > (uint32_t)LDS_LEVELS ? ctx->stack_need - LDS_LEVELS : 0u;
-    if ((rc = dev_alloc(ctx, r.allocs, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
-    ps.n_slots = (uint32_t)total;
+    if ((rc = dev_alloc(ctx, r.allocs, &r.tick_rays, (size_t)pt_context::ROLL_RING))) return rc;
     ps.region_cap = cap;
     r.ps = ps;
     r.n_regions = n_regions;
     r.cap = cap;
+    r.n_live = n_live;
+    r.counted = r.tick;
+    r.known_rays = 0;
     return PT_OK;
 }
 
 // Bytes ensure_roll allocates per pipe, near enough.
-static uint64_t roll_bytes(const pt_context *ctx, uint64_t n_regions, uint64_t cap) {
-    const uint64_t total = n_regions * cap;
-    uint64_t max_chunks, max_ray_chunks;
-    queue_capacity(ctx, total, max_chunks, max_ray_chunks);
-    return total * (ctx->nee ? 100u : 84u) + (max_ray_chunks * (ctx->nee ? 3u : 2u) + max_chunks * ctx->n_queues) * QUEUE_CHUNK * 4u;
+static uint64_t roll_bytes(const pt_context *ctx, uint64_t n_regions, uint64_t cap, uint64_t n_live) {
+    uint64_t unused, max_ray_chunks, max_chunks, max_shadow_chunks;
+    queue_capacity(ctx, n_live, unused, max_ray_chunks);
+    queue_capacity(ctx, n_live + cap, max_chunks, max_shadow_chunks);
+    const uint64_t positions = max_ray_chunks * QUEUE_CHUNK;
+    return n_regions * cap * 16u + positions * (2u * 52u + 20u) + cap * 20u + max_chunks * QUEUE_CHUNK * 4u * ctx->n_queues +
+           (ctx->nee ? max_shadow_chunks * QUEUE_CHUNK * 52u : 0u);
+}
+// Rays in flight a rolling pipe has room for, given the paths started per launch.
+static uint64_t roll_live(const pt_context *ctx, uint32_t depth, uint64_t cap) {
+    const double f = std::min<double>(std::max(ctx->live_factor, 2.0), (double)depth);
+    return (uint64_t)(f * (double)cap);
 }
 
 static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
@@ -1274,21 +1276,50 @@ static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
     ctx->profiled_batches++;
 }
 
-// One tick of the next pipe in turn.  `nb` (may be null): the batch to start with it; bp->n_slots <= cap.
-static int roll_step(pt_context *ctx, const BatchParams *nb) {
+// One tick of the next pipe in turn.  `nb` (may be null): the batch to start with it; nb->n_slots <= cap.
+// *started (may be null when nb is): whether the batch did start: it does not when its paths and the rays in
+// flight might not fit the pipe's arrays, and the tick then only advances what is under way.
+static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nullptr) {
     const int p = (int)(ctx->roll_seq % (uint64_t)ctx->n_roll_pipes);
     pt_context::Pipe &pp = ctx->pipes[p];
     pt_context::Roll &r = ctx->rolls[p];
     const int ring = (int)(r.tick % pt_context::ROLL_RING);
-    if (r.tick >= (uint64_t)pt_context::ROLL_RING) {
+    auto wait_for = [&](uint64_t tick) -> int {
         auto w0 = std::chrono::steady_clock::now();
-        HIP_TRY(ctx, hipEventSynchronize(r.done[ring]));
+        HIP_TRY(ctx, hipEventSynchronize(r.done[tick % pt_context::ROLL_RING]));
         ctx->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        return PT_OK;
+    };
+    auto count_finished = [&]() {  // ticks finish in order
+        while (r.counted < r.tick && hipEventQuery(r.done[r.counted % pt_context::ROLL_RING]) == hipSuccess) {
+            r.known_rays = r.host_tick_rays[r.counted % pt_context::ROLL_RING];
+            r.counted++;
+        }
+    };
+    if (r.tick >= (uint64_t)pt_context::ROLL_RING) {  // this tick reuses the ring entry of the tick ROLL_RING before it
+        if (int rc = wait_for(r.tick)) return rc;
         harvest_roll(ctx, r, ring);
     }
+    count_finished();
+    if (nb) {
+        // rays queued for this tick <= what the last finished tick queued + the paths started since
+        for (;;) {
+            uint64_t in_flight = r.known_rays;
+            for (uint64_t t = r.counted; t < r.tick; t++) in_flight += r.ring_new[t % pt_context::ROLL_RING];
+            if (in_flight + nb->n_slots <= r.n_live) break;
+            if (r.counted == r.tick) {  // everything is known and there is no room: this tick starts nothing
+                nb = nullptr;
+                break;
+            }
+            if (int rc = wait_for(r.counted)) return rc;
+            count_finished();
+        }
+    }
+    if (started) *started = nb != nullptr;
     hipStream_t st = pp.stream;
     r.ps.refill_below = ctx->refill_below;
     r.ps.leaf_batch = ctx->leaf_batch;
+    r.ps.next_rays = r.tick_rays + ring;
     const PathState ps = r.ps;
     const uint32_t depth = ctx->cam.max_depth;
     const uint32_t region = (uint32_t)(r.tick % r.n_regions), base = region * r.cap;
@@ -1296,17 +1327,18 @@ static int roll_step(pt_context *ctx, const BatchParams *nb) {
     const bool prof = ctx->profile;
     if (prof) (void)hipEventRecord(r.prof[ring][0], st);
     FreshPaths fp{base, 0u};
+    RegionParams rp{};
     if (nb) {
         fp.n_new = nb->n_slots;
-        RegionParams rp{};
         rp.seed_mixed = nb->seed_mixed;
         rp.stratum_first = nb->stratum_first;
         rp.n_strata = nb->n_strata;
-        hipLaunchKernelGGL(k_set_region, dim3(1), dim3(1), 0, st, ps.regions, region, rp);
         r.due.push_back({r.tick + depth - 1u, region, nb->n_strata});
     }
+    r.ring_new[ring] = fp.n_new;
+    hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(1), 0, st, ps.regions, region, rp, nb ? 1u : 0u, ps.next_rays);
     if (prof) (void)hipEventRecord(r.prof[ring][1], st);
-    const uint64_t bound = (uint64_t)r.n_regions * r.cap;
+    const uint64_t bound = r.n_live + r.cap;
     launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp);
     if (prof) (void)hipEventRecord(r.prof[ring][2], st);
     BatchParams common{};
@@ -1316,6 +1348,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb) {
     const int grid_shade = grid_fixed(ctx, bound, ctx->shade_blocks_per_cu);
     for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, fp});
     if (ctx->nee) launch_shadow(ctx, st, grid_fixed(ctx, bound), ps, parity);
+    HIP_TRY(ctx, hipMemcpyAsync(r.host_tick_rays + ring, ps.next_rays, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (prof) {
         (void)hipEventRecord(r.prof[ring][3], st);
         r.prof_pending[ring] = true;
@@ -1357,7 +1390,7 @@ static uint32_t roll_strata(pt_context *ctx) {
 }
 static uint32_t roll_strata_now(pt_context *ctx) {
     const uint32_t depth = ctx->cam.max_depth;
-    if (ctx->roll_paths == 0 || ctx->counters || !ctx->use_wide() || depth == 0 || depth > 256) return 0;
+    if (ctx->roll_paths == 0 || ctx->counters || !ctx->use_wide() || depth == 0) return 0;
     const uint64_t npix = (uint64_t)ctx->cam.width * ctx->cam.height;
     uint64_t k = std::max<uint64_t>(1, std::min(ctx->roll_paths, ctx->max_paths) / npix);
     size_t free_b = 0, total_b = 0;
@@ -1366,8 +1399,9 @@ static uint32_t roll_strata_now(pt_context *ctx) {
     for (int p = 0; p < ctx->n_roll_pipes; p++)
         for (const auto &a : ctx->rolls[p].allocs) have += a.second;  // what is there would be replaced
     const uint64_t budget = have / 2 / (uint64_t)ctx->n_roll_pipes;
-    while (k > 1 && roll_bytes(ctx, depth, npix * k) > budget) k--;
-    if (roll_bytes(ctx, depth, npix * k) > budget || (uint64_t)depth * npix * k > (1ull << 31)) return 0;
+    auto bytes = [&](uint64_t kk) { return roll_bytes(ctx, depth, npix * kk, roll_live(ctx, depth, npix * kk)); };
+    while (k > 1 && bytes(k) > budget) k--;
+    if (bytes(k) > budget || (uint64_t)depth * npix * k > (1ull << 31)) return 0;
     return (uint32_t)k;
 }
 
@@ -1381,8 +1415,6 @@ static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
         return fail(ctx, PT_ERR_INVALID, "BSDF_SAMPLE_PROBABILITY below 1 needs a light to sample, and the scene has none");
     if (ctx->nee && (ctx->scene.n_media != 0 || ctx->scene.n_moving != 0))
         return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation does not handle participating media or moving spheres");
-    if (ctx->scene.n_moving != 0 && (ctx->counters || !ctx->use_wide()))
-        return fail(ctx, PT_ERR_UNSUPPORTED, "moving spheres are handled by the ray-drawing traversal only (no test counters, no reference-order traversal)");
     if (ctx->nee && (ctx->counters || !ctx->use_wide()))
         return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation runs on the ray-drawing traversal only (no test counters, no reference-order traversal)");
     return PT_OK;
@@ -1406,18 +1438,20 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     }
     if (const uint32_t k_tick = roll_strata(ctx)) {
         const uint32_t depth = ctx->cam.max_depth, cap_slots = npix * k_tick;
+        const uint64_t n_live = roll_live(ctx, depth, cap_slots);
         bool fits = true;
-        for (int p = 0; p < ctx->n_roll_pipes; p++) fits = fits && ctx->rolls[p].n_regions == depth && ctx->rolls[p].cap == cap_slots;
+        for (int p = 0; p < ctx->n_roll_pipes; p++) fits = fits && ctx->rolls[p].n_regions == depth && ctx->rolls[p].cap == cap_slots && ctx->rolls[p].n_live == n_live;
         if (!fits) {
             sync_pipes(ctx);
             for (int p = 0; p < ctx->n_roll_pipes; p++)
-                if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], depth, cap_slots))) return rc;
+                if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], depth, cap_slots, n_live))) return rc;
         }
         const uint32_t n_batches = (total + k_tick - 1) / k_tick, per_batch = (total + n_batches - 1) / n_batches;
         for (uint32_t s = stratum_begin; s < stratum_end;) {
             const uint32_t k = std::min(per_batch, stratum_end - s);
             BatchParams bp{mix64_host(seed), s, k, npix, npix * k, ctx->bsdf_prob, ctx->cam.background};
-            if ((rc = roll_step(ctx, &bp))) return rc;
+            for (bool started = false; !started;)  // ticks that cannot take the batch yet still advance the paths under way
+                if ((rc = roll_step(ctx, &bp, &started))) return rc;
             ctx->n_samples += k;
             s += k;
         }
@@ -1638,8 +1672,8 @@ int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_
     if (!base) return fail(ctx, PT_ERR_STATE, "no static scratch on device %d", ctx->device);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     PathState ps{};
-    ps.ray_o = (float4 *)(base + STATIC_OFF_RAY_O);
-    ps.ray_d = (float4 *)(base + STATIC_OFF_RAY_D);
+    ps.ray_o[0] = (float4 *)(base + STATIC_OFF_RAY_O);
+    ps.ray_d[0] = (float4 *)(base + STATIC_OFF_RAY_D);
     ps.hit = (float4 *)(base + STATIC_OFF_HIT);
     ps.hit2 = (uint32_t *)(base + STATIC_OFF_HIT2);
     ps.ray_queue[0] = (uint32_t *)(base + STATIC_OFF_QUEUE);

@@ -96,27 +96,43 @@ def test_per_sample_radiance_identical_across_options():
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-@pytest.mark.parametrize("make,width", [(scenes.small_mixed, 32), (scenes.cornell, 48)])
-def test_accumulator_identical_wherever_the_tail_launch_takes_over(make, width):
-    # The tail launch starts once the host has the ray counts of an earlier batch of the same pipe,
-    # so render many small batches: 0 = never, 1e9 = from bounce 1, the others in between.
-    from pathtracer_amd.core import PT_OPT_MAX_PATHS, PT_OPT_PIPES, PT_OPT_TAIL_BELOW
-    src = make(width, 36)  # square images, 36 strata
-    npix = width * width
+def test_tail_option_is_accepted_and_changes_nothing():
+    # PT_OPT_TAIL_BELOW belonged to an earlier schedule; callers that still set it get the same sums
+    from pathtracer_amd.core import PT_OPT_TAIL_BELOW
+    src = scenes.small_mixed(32, 36)
+    accs = []
+    for tail in (0, 600, 1_000_000_000):
+        r = _renderer(src)
+        r.set_option(PT_OPT_TAIL_BELOW, tail)
+        r.render(0, 31, seed=5)
+        accs.append(r.read_accum()[0])
+    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
+    assert np.array_equal(accs[0].view(np.uint32), accs[2].view(np.uint32))
+
+
+@pytest.mark.parametrize("make,width", [(scenes.cornell, 48), (scenes.interior, 64)])
+def test_accumulator_identical_however_few_rays_may_be_in_flight(make, width):
+    # PT_OPT_LIVE_FACTOR sizes the travelling path state as a multiple of the paths started per launch.
+    # These scenes keep 2.5 to 4 rays alive per started path, so a factor of 2 makes the host hold
+    # batches back until earlier ones have thinned out; the sums must not notice, and no queue may
+    # run out of room (sync reports that as an error).
+    from pathtracer_amd.core import PT_OPT_LIVE_FACTOR, PT_OPT_PIPES, PT_OPT_ROLLING
+    src = make(width, 36)
+    npix = src.camera.image_width * max(1, int(src.camera.image_width / src.camera.aspect_ratio))
     ref = None
-    for pipes, tail in ((1, 0), (1, 1_000_000_000), (1, 8192), (1, 600), (1, 40), (2, 600), (4, 1_000_000_000)):
+    for pipes, rolling, factor in ((1, 0, 4), (1, npix, 2), (1, 3 * npix, 2), (2, 2 * npix, 2), (1, npix, 3), (2, npix, 50), (1, 5 * npix + 7, 2.5)):
         r = _renderer(src)
         r.set_option(PT_OPT_PIPES, pipes)
-        r.set_option(PT_OPT_MAX_PATHS, 2 * npix)
-        r.set_option(PT_OPT_TAIL_BELOW, tail)
-        r.render(0, 16, seed=5)
-        r.render(16, 31, seed=5)
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.set_option(PT_OPT_LIVE_FACTOR, factor)
+        r.render(0, 20, seed=5)
+        r.render(20, 36, seed=5)
         acc, n = r.read_accum()
-        assert n == 31
+        assert n == 36
         if ref is None:
             ref = acc
         else:
-            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} tail_below={tail}"
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} rolling={rolling} factor={factor}"
 
 
 @pytest.mark.parametrize("make,width", [(scenes.small_mixed, 32), (scenes.cornell, 48)])
@@ -155,8 +171,8 @@ def test_rolling_schedule_survives_setting_changes_between_calls():
     assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
 
 
-def test_deep_paths_fall_back_to_one_batch_at_a_time():
-    # more than 256 bounces: the rolling schedule (one region of path state per bounce) steps aside; same sums
+def test_deep_paths_give_the_same_sums_under_both_schedules():
+    # 300 bounces allowed: 300 regions of per-slot sums under the rolling schedule
     from pathtracer_amd.core import PT_OPT_ROLLING
     src = scenes.cornell(32, 16, max_depth=300)
     accs = []
@@ -169,8 +185,8 @@ def test_deep_paths_fall_back_to_one_batch_at_a_time():
 
 
 def test_new_option_ranges_are_checked():
-    from pathtracer_amd.core import PT_OPT_DEVICE_BVH, PT_OPT_INTEGRATOR, PT_OPT_ROLLING, PT_OPT_TAIL_BELOW, PtError
+    from pathtracer_amd.core import PT_OPT_DEVICE_BVH, PT_OPT_INTEGRATOR, PT_OPT_LIVE_FACTOR, PT_OPT_ROLLING, PT_OPT_TAIL_BELOW, PtError
     r = _renderer(cornell_small())
-    for key, bad in ((PT_OPT_ROLLING, -1), (PT_OPT_TAIL_BELOW, -1), (PT_OPT_INTEGRATOR, 2), (PT_OPT_INTEGRATOR, 0.5), (PT_OPT_DEVICE_BVH, -3)):
+    for key, bad in ((PT_OPT_ROLLING, -1), (PT_OPT_TAIL_BELOW, -1), (PT_OPT_LIVE_FACTOR, 1.5), (PT_OPT_INTEGRATOR, 2), (PT_OPT_INTEGRATOR, 0.5), (PT_OPT_DEVICE_BVH, -3)):
         with pytest.raises(PtError):
             r.set_option(key, bad)

@@ -77,12 +77,30 @@ def test_device_restatement_against_the_oracle_per_sample(which):
 
 @pytest.mark.gpu
 def test_modes_that_do_not_handle_moving_spheres_say_so():
-    from pathtracer_amd.core import PT_OPT_INTEGRATOR, PT_OPT_TRAVERSAL, HostScene, PtError, Renderer
-    for key in (PT_OPT_INTEGRATOR, PT_OPT_TRAVERSAL):
-        r = Renderer(HostScene(_scene((0, 0, 0), (1, 0, 0), depth=4, spp=4)))
+    from pathtracer_amd.core import PT_OPT_INTEGRATOR, HostScene, PtError, Renderer
+    r = Renderer(HostScene(_scene((0, 0, 0), (1, 0, 0), depth=4, spp=4)))
+    r.set_option(PT_OPT_INTEGRATOR, 1)  # next-event estimation keeps the density of the last vertex where the time rides
+    with pytest.raises(PtError):
+        r.render(0, 1, seed=1)
+
+
+@pytest.mark.gpu
+def test_reference_order_traversal_and_counters_see_moving_spheres():
+    """The reference's loop over 32-byte nodes (and the counting variant of it) tests the moving spheres last, like the
+    ray-drawing traversal: same samples bit for bit, and every ray counts one sphere test per moving sphere."""
+    from pathtracer_amd.core import PT_OPT_COUNTERS, PT_OPT_TRAVERSAL, HostScene, Renderer
+    src = _scene((-1.5, 0.0, 0.0), (1.5, 0.3, 0.5), width=40, spp=16, depth=6, extras=True)
+    host = HostScene(src)
+    want = Renderer(host).render_samples(0, 8, seed=4)
+    for key in (PT_OPT_TRAVERSAL, PT_OPT_COUNTERS):
+        r = Renderer(host)
         r.set_option(key, 1)
-        with pytest.raises(PtError):
-            r.render(0, 1, seed=1)
+        r.stats_reset()
+        got = r.render_samples(0, 8, seed=4)
+        assert np.array_equal(np.nan_to_num(got).view(np.uint32), np.nan_to_num(want).view(np.uint32)), key
+        if key == PT_OPT_COUNTERS:
+            st = r.stats()
+            assert st["sphere_tests"] >= 2 * st["rays"]  # two moving spheres in this scene
 
 
 @pytest.mark.gpu

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""The knob/Disney render from start to finish, the one figure that stands beside the reference's README
+(README.md:10: "10240 spp", about 1500 s on its author's machine): scene authoring, host BVH build, upload, all
+101^2 = 10201 stratified passes at 768x768 and depth 50 (src/scenes/object.rs:73-94, src/camera.rs:119-121), and the
+8-bit image back on the host.  Also renders 256 passes with the CPU oracle and with the device (different seeds) and
+applies the stated image rule (RMSE and mean relative error within twice the oracle's own two-seed figures).
+
+    python tools/c3_full.py [out.json] [--devices 0,1,...]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pathtracer_amd import scenes  # noqa: E402
+from pathtracer_amd.core import GroupRenderer, HostScene  # noqa: E402
+
+
+def image_errors(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2))), float(np.mean(np.abs(a - b)) / max(1e-12, np.mean(np.abs(b))))
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(ROOT, "gpurun_out", "c3_full.json")
+    devices = [0]
+    for k, a in enumerate(sys.argv):
+        if a == "--devices":
+            devices = [int(x) for x in sys.argv[k + 1].split(",")]
+    t0 = time.perf_counter()
+    src = scenes.knob()  # 768 wide, 10240 spp, depth 50
+    t_author = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    host = HostScene(src)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g = GroupRenderer(host, devices)
+    t_upload = time.perf_counter() - t0
+    total = g.sqrt_spp * g.sqrt_spp
+    t0 = time.perf_counter()
+    for b in range(0, total, 1024):  # the display image is refreshed between calls, as a progressive viewer would
+        g.render(b, min(total, b + 1024), seed=1)
+        img = g.read_rgb8()
+    t_render = time.perf_counter() - t0
+    acc, n = g.read_accum()
+    st = g.stats()
+    assert n == total
+    res = {
+        "workload": f"knob scene {g.width}x{g.height}, depth {src.camera.max_depth}, {host.desc.n_tris} triangles (procedural stand-in for mitsuba_smooth.obj), "
+                    f"{total} stratified passes (spp 10240 -> 101^2), devices {devices}",
+        "seconds": {"scene_authoring_python": t_author, "host_bvh_build": t_build, "context_and_upload": t_upload, "render_and_readback": t_render,
+                    "total": t_author + t_build + t_upload + t_render},
+        "passes": total, "spp_per_s": total / t_render, "rays": st["rays"], "Mrays_per_s": st["rays"] / t_render / 1e6,
+        "mean_path_length": st["rays"] / max(1, st["paths"]), "device_bytes": st["device_bytes"],
+        "image_mean_8bit": float(img.mean()), "image_sha256": hashlib.sha256(img.tobytes()).hexdigest(),
+        "accum_mean_per_pass": float(acc.mean() / n),
+        "reference_readme": "about 1500 s for the same pass count on unstated hardware (README.md:10)",
+    }
+    with open(os.path.splitext(out_path)[0] + ".ppm", "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (g.width, g.height) + img.tobytes())
+    # the image rule at 256 passes
+    from oracle.pyoracle import OracleScene
+    o = OracleScene(src)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    a = o.render(0, 256, seed=1, threads=threads)["accum"] / 256
+    t_oracle = time.perf_counter() - t0
+    b = o.render(0, 256, seed=2, threads=threads)["accum"] / 256
+    g.reset_accum()
+    g.render(0, 256, seed=3)
+    d, n256 = g.read_accum()
+    d = d / n256
+    floor_rmse, floor_mre = image_errors(a, b)
+    rmse, mre = image_errors(d, a)
+    res["image_rule_256_passes"] = {"rmse_device_vs_oracle": rmse, "rmse_oracle_two_seeds": floor_rmse, "mre_device_vs_oracle": mre, "mre_oracle_two_seeds": floor_mre,
+                                    "within_twice_the_floor": bool(rmse <= 2 * floor_rmse and mre <= 2 * floor_mre),
+                                    "mean_device": float(d.mean()), "mean_oracle": float(a.mean()),
+                                    "oracle_seconds_256_passes": t_oracle, "oracle_threads": threads}
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res))
+    g.close()
+
+
+if __name__ == "__main__":
+    main()
