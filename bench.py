@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: Mrays/s and spp/s on the knob/Disney scene at 768x768.
 
-One "step" renders ``--strata-per-step`` full-frame stratified passes (every pixel, one path
+One "step" renders ``--strata-per-step`` (256) full-frame stratified passes (every pixel, one path
 each, depth 50) on each GPU; ranks own disjoint stratum ranges (no data-path collective)
 and the float accumulators are summed onto rank 0 with one reduce at the end of the timed
 region.  Rank 0 prints one JSON line.
@@ -25,6 +25,9 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per tested item (what one ray must read at minimum)
 B_NODE, B_TRI, B_SPHERE, B_QUAD, B_RAY_IO = 32, 36, 16, 64, 32 + 16
 HBM_PEAK_GBS = 8000.0
+# wave64 vector instructions the chip can issue per second: 256 CUs x 4 SIMDs x 2.4 GHz, one every 2 cycles
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
+COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")  # tools/pmc_counters.py over this command
 
 
 def cpu_baseline(src, budget_s: float = 12.0, bsdf_probability: float = 1.0):
@@ -56,14 +59,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=768)
-    ap.add_argument("--strata-per-step", type=int, default=128)
+    ap.add_argument("--strata-per-step", type=int, default=256)
     ap.add_argument("--scene", default="knob", choices=["knob", "cornell", "dragon_box", "interior", "next_week_like"])
     ap.add_argument("--pipes", type=int, default=0, help="batches in flight per GPU (0: library default)")
     ap.add_argument("--refill-below", type=int, default=0)
     ap.add_argument("--leaf-batch", type=int, default=0)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tail-below", type=int, default=-1)
-    ap.add_argument("--rolling", type=int, default=12_000_000,
+    ap.add_argument("--rolling", type=int, default=-1,
                     help="paths started per launch of the rolling schedule (0: one batch at a time per pipe; -1: library default)")
     ap.add_argument("--live-factor", type=float, default=0.0, help="rays in flight a pipe has room for, as a multiple of the paths started per launch (0: library default)")
     ap.add_argument("--integrator", default="reference", choices=["reference", "nee"],
@@ -72,6 +75,7 @@ def main():
                     help="BSDF_SAMPLE_PROBABILITY of the reference's mixture sampler (src/camera.rs:317); below 1 some rays are aimed at lights")
     ap.add_argument("--lights", type=int, default=64, help="interior: number of emissive quads")
     ap.add_argument("--extensions", action="store_true", help="next_week_like with its noise texture, media and moving sphere")
+    ap.add_argument("--max-depth", type=int, default=0, help="knob: override the scene's depth of 50 (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -87,7 +91,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_MAX_PATHS, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -97,7 +101,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    builders = {"knob": lambda: scenes.knob(width=args.width), "cornell": lambda: scenes.cornell(width=args.width),
+    builders = {"knob": lambda: scenes.knob(width=args.width, **({"max_depth": args.max_depth} if args.max_depth else {})), "cornell": lambda: scenes.cornell(width=args.width),
                 "dragon_box": lambda: scenes.dragon_box(width=args.width), "interior": lambda: scenes.interior(width=args.width, n_lights=args.lights),
                 "next_week_like": lambda: scenes.next_week_like(width=args.width, extensions=args.extensions)}
     src = builders[args.scene]()
@@ -116,6 +120,8 @@ def main():
     if args.tail_below >= 0:
         r.set_option(PT_OPT_TAIL_BELOW, args.tail_below)
     if args.rolling >= 0:
+        if args.rolling > 24_000_000:  # beyond the library's default cap on paths per batch
+            r.set_option(PT_OPT_MAX_PATHS, args.rolling)
         r.set_option(PT_OPT_ROLLING, args.rolling)
     if args.live_factor:
         r.set_option(PT_OPT_LIVE_FACTOR, args.live_factor)
@@ -181,32 +187,40 @@ def main():
         try:
             step(args.warmup)
             sc = r.stats()
-        except Exception as e:  # scenes with moving spheres have no counting traversal
+        except Exception as e:
             print(f"no counted pass: {e}", file=sys.stderr)
             sc = {"rays": 0, "node_tests": 0, "tri_tests": 0, "sphere_tests": 0, "quad_tests": 0}
         r.set_option(PT_OPT_COUNTERS, 0)
         rays_c = max(1, sc["rays"])
         b_ray = (B_NODE * sc["node_tests"] + B_TRI * sc["tri_tests"] + B_SPHERE * sc["sphere_tests"] + B_QUAD * sc["quad_tests"]) / rays_c + B_RAY_IO
-        # The closest-hit kernel on this rank over the timed region.  Launches of different batches
-        # overlap (several batches are in flight, each on its own stream), so the rate is taken over
-        # the time during which at least one launch was running; the per-launch figures are averages
-        # over the launches that had rays, each bracketed by HIP events on its own stream.
+        # The closest-hit kernel on this rank over the timed region: averages over the launches that
+        # had rays, each bracketed by HIP events on its own stream.  Launches of different pipes overlap
+        # (each pipe has its own stream), so a launch shares the chip with the other pipe's kernels for
+        # part of its duration; the rate over the union of the launch intervals is reported beside it.
         launches = max(1, st["extend_launches"])
         ext_ms_per_launch = st["extend_ms"] / launches
         rays_per_launch = st["rays"] / launches
         busy_s = st["extend_busy_ms"] * 1e-3
-        achieved = st["rays"] * b_ray / busy_s / 1e9 if busy_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if args.scene == "knob" and os.path.exists(tpath):  # HBM bytes per ray from rocprofv3 --pmc passes over this command
-            with open(tpath) as f:
-                traffic = json.load(f)["hbm_bytes_per_ray"] * rays_per_launch
+        union_busy = st["rays"] * b_ray / busy_s / 1e9 if busy_s > 0 else 0.0
+        launch_s = ext_ms_per_launch * 1e-3
+        achieved = rays_per_launch * b_ray / launch_s / 1e9 if launch_s > 0 else 0.0
+        # counter-based figures: per-ray numbers of the committed rocprofv3 --pmc passes over this command,
+        # scaled by this run's rays per launch and divided by this run's launch duration
+        traffic = hbm_counter_frac = valu_issue_frac = lane_util = None
+        if args.scene == "knob" and args.width == 768 and os.path.exists(COUNTERS) and launch_s > 0:
+            with open(COUNTERS) as f:
+                pc = json.load(f)
+            traffic = pc["hbm_bytes_per_ray"] * rays_per_launch
+            hbm_counter_frac = traffic / launch_s / (HBM_PEAK_GBS * 1e9)
+            valu_issue_frac = pc["valu_per_ray"] * rays_per_launch / launch_s / VALU_ISSUE_PEAK
+            lane_util = pc["lane_util"]
         out = {
             "metric": "Mrays/s & spp/s, mitsuba knob 768^2 Disney" if args.scene == "knob" else f"Mrays/s & spp/s, {args.scene}",
             "value": rays_all / dt / 1e6,
             "unit": "Mrays/s",
             "spp_per_s": args.steps * S * world / dt,
             "paths_per_s": paths_all / dt,
+            "rays": rays_all,
             "mean_path_length": rays_all / max(1.0, paths_all),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -219,12 +233,13 @@ def main():
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce",
                        "integrator": args.integrator, "bsdf_sample_probability": args.bsdf_probability,
                        "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
-                                    "library default" if args.rolling < 0 else "one batch at a time per pipe")},
+                                    "library default (rolling, one pipe, up to 24 M paths started per launch)" if args.rolling < 0 else "one batch at a time per pipe")},
             "roofline": {"bound": "hbm", "kernel": "k_extend_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "hbm_counter_frac": hbm_counter_frac, "valu_issue_frac": valu_issue_frac, "lane_util": lane_util,
                          "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
                          "launches": st["extend_launches"], "busy_ms": st["extend_busy_ms"],
-                         "achieved_per_launch": (rays_per_launch * b_ray / (ext_ms_per_launch * 1e-3) / 1e9) if ext_ms_per_launch > 0 else 0.0,
+                         "achieved_over_union_of_launches": union_busy,
                          "launches_in_flight": st["extend_ms"] / st["extend_busy_ms"] if st["extend_busy_ms"] > 0 else 0.0,
                          "node_tests_per_ray": sc["node_tests"] / rays_c, "tri_tests_per_ray": sc["tri_tests"] / rays_c},
             "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "other": st["other_ms"]},

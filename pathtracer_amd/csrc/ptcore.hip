@@ -42,7 +42,7 @@ struct pt_context {
 
     // options
     float bsdf_prob = 1.0f;
-    uint64_t max_paths = 1ull << 24;
+    uint64_t max_paths = 24000000;
     bool profile = false, counters = false;
     bool force_ref_order = false;  // PT_OPT_TRAVERSAL = 1
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
@@ -57,6 +57,7 @@ struct pt_context {
     bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
     uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
     double live_factor = 4.0;  // PT_OPT_LIVE_FACTOR
+    bool shade_spread = getenv("PT_SHADE_SPREAD") ? atoi(getenv("PT_SHADE_SPREAD")) != 0 : true;
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -78,6 +79,12 @@ struct pt_context {
     // pipes[0] runs on `stream` and also serves the first-hit and per-sample entry points.
     struct Pipe {
         hipStream_t stream = nullptr;
+        // The shading launches of one step (one per material type) are independent of each other: those
+        // after the first go to these streams, between a fork and a join on `stream`, so that a
+        // launch with few hits does not have the chip to itself.
+        static constexpr int N_SIDE = 2;
+        hipStream_t side[N_SIDE] = {nullptr, nullptr};
+        hipEvent_t fork = nullptr, join[N_SIDE] = {nullptr, nullptr};
         PathState ps{};
         std::vector<std::pair<void *, size_t>> allocs;
         uint64_t capacity = 0;
@@ -126,9 +133,9 @@ struct pt_context {
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
     int64_t roll_k = -1;             // strata per tick decided for the current scene, camera and options (-1: not yet)
     uint64_t untraced_paths = 0;  // camera paths of renders with max_depth 0, which start and end on the host
-    uint64_t roll_paths = 12000000;  // paths started per tick; 0 = one batch at a time per pipe
+    uint64_t roll_paths = 24000000;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;       // batch-at-a-time schedule
-    int n_roll_pipes = 2;  // rolling schedule: its launches are all large, two pipes cover each other's ramps
+    int n_roll_pipes = 1;  // rolling schedule: its launches are all large; a second pipe gains 0-3 % and doubles the path state
     uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
     hipEvent_t last_accumulated = nullptr;  // of the most recent batch: the next k_accumulate waits for it
     // Rays per bounce of the most recent finished batch ([0] = its paths): launches of later batches are
@@ -252,6 +259,14 @@ static void destroy_pipes(pt_context *ctx) {
             if (hc) (void)hipHostFree(hc);
             hc = nullptr;
         }
+        for (int k = 0; k < pt_context::Pipe::N_SIDE; k++) {
+            if (pp.side[k]) (void)hipStreamDestroy(pp.side[k]);
+            if (pp.join[k]) (void)hipEventDestroy(pp.join[k]);
+            pp.side[k] = nullptr;
+            pp.join[k] = nullptr;
+        }
+        if (pp.fork) (void)hipEventDestroy(pp.fork);
+        pp.fork = nullptr;
         if (pp.stream) (void)hipStreamDestroy(pp.stream);
         pp.stream = nullptr;
     }
@@ -366,6 +381,11 @@ int pt_create(int device, pt_context **out) {
     e = hipEventCreate(&ctx->epoch);
     for (int i = 0; i < pt_context::MAX_PIPES && e == hipSuccess; i++) {
         if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].fork, hipEventDisableTiming);
+        for (int k = 0; k < pt_context::Pipe::N_SIDE && e == hipSuccess; k++) {
+            e = hipStreamCreateWithFlags(&ctx->pipes[i].side[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].join[k], hipEventDisableTiming);
+        }
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated[k], hipEventDisableTiming);
         for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc((void **)&ctx->pipes[i].host_chunks[k], BOUNCE_PROFILE_LEN * sizeof(uint32_t), hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->rolls[i].host_tick_rays, pt_context::ROLL_RING * sizeof(uint32_t), hipHostMallocDefault);
@@ -1114,6 +1134,29 @@ static void launch_shade(const ShadeLaunch &l) {
     else SHADE(0);
 #undef SHADE
 }
+static void launch_shade_type(int type, const ShadeLaunch &l);
+// The shading launches of one step, one per material type in the scene, spread over the pipe's streams.
+static int launch_shades(pt_context *ctx, pt_context::Pipe &pp, ShadeLaunch l) {
+    constexpr int N_SIDE = pt_context::Pipe::N_SIDE;
+    const hipStream_t st = pp.stream;
+    const bool spread = ctx->shade_spread && ctx->n_queues > 1;
+    if (spread) {
+        HIP_TRY(ctx, hipEventRecord(pp.fork, st));
+        for (int k = 0; k < N_SIDE && k + 1 < (int)ctx->n_queues; k++) HIP_TRY(ctx, hipStreamWaitEvent(pp.side[k], pp.fork, 0));
+    }
+    for (uint32_t q = 0; q < ctx->n_queues; q++) {
+        const int lane = spread ? (int)(q % (N_SIDE + 1)) : 0;
+        l.st = lane == 0 ? st : pp.side[lane - 1];
+        l.q = q;
+        launch_shade_type(ctx->queue_type[q], l);
+    }
+    if (spread)
+        for (int k = 0; k < N_SIDE && k + 1 < (int)ctx->n_queues; k++) {
+            HIP_TRY(ctx, hipEventRecord(pp.join[k], pp.side[k]));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, pp.join[k], 0));
+        }
+    return PT_OK;
+}
 static void launch_shade_type(int type, const ShadeLaunch &l) {
     switch (type) {
         case PTS_MAT_LAMBERTIAN: launch_shade<PTS_MAT_LAMBERTIAN>(l); break;
@@ -1216,7 +1259,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
         const FreshPaths fp{0u, b == 0u ? (uint32_t)n_slots : 0u};  // every path of the batch starts with its first step
         launch_extend(ctx, st, g_ext, ps, b, fp);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
-        for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, q, fp});
+        if ((rc = launch_shades(ctx, pp, ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, 0u, fp}))) return rc;
         if (ctx->nee) launch_shadow(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
@@ -1346,7 +1389,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
     common.bsdf_prob = ctx->nee ? 1.0f : ctx->bsdf_prob;
     common.background = ctx->cam.background;
     const int grid_shade = grid_fixed(ctx, bound, ctx->shade_blocks_per_cu);
-    for (uint32_t q = 0; q < ctx->n_queues; q++) launch_shade_type(ctx->queue_type[q], ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, q, fp});
+    if (int rc = launch_shades(ctx, pp, ShadeLaunch{ctx, st, &ps, grid_shade, &common, parity, 0u, fp})) return rc;
     if (ctx->nee) launch_shadow(ctx, st, grid_fixed(ctx, bound), ps, parity);
     HIP_TRY(ctx, hipMemcpyAsync(r.host_tick_rays + ring, ps.next_rays, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     if (prof) {

@@ -7,5 +7,14 @@ run c1_cornell_256 --scene cornell --width 256 --strata-per-step 64 --steps 20 -
 run c2_next_week_800 --scene next_week_like --extensions --width 800
 run c3_knob_768 --scene knob --width 768
 run c4_dragon_1024 --scene dragon_box --width 1024
-run c5_interior_1920_p05 --scene interior --width 1920 --strata-per-step 32 --bsdf-probability 0.5
-run c5_interior_1920_nee --scene interior --width 1920 --strata-per-step 32 --integrator nee
+run c5_interior_1920_p05 --scene interior --width 1920 --strata-per-step 64 --bsdf-probability 0.5
+run c5_interior_1920_nee --scene interior --width 1920 --strata-per-step 64 --integrator nee
+python3 - <<'PY'
+import glob, json
+rows = {}
+for f in sorted(glob.glob("gpurun_out/cfg_*.json")):
+    with open(f) as fh:
+        rows[f.split("cfg_")[1][:-5]] = json.loads(fh.read().strip().splitlines()[-1])
+with open("gpurun_out/all_configs.json", "w") as fh:
+    json.dump(rows, fh, indent=1)
+PY

@@ -7,7 +7,7 @@ set -e
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="${1:-$R/gpurun_out/pmc}"
 shift || true
-ARGS="${@:---steps 1 --warmup 1 --no-cpu-baseline}"
+ARGS="${@:---steps 2 --warmup 0 --no-cpu-baseline}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 pass() {
