@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--lights", type=int, default=64, help="interior: number of emissive quads")
     ap.add_argument("--extensions", action="store_true", help="next_week_like with its noise texture, media and moving sphere")
     ap.add_argument("--max-depth", type=int, default=0, help="knob: override the scene's depth of 50 (experiments only)")
+    ap.add_argument("--packet", type=int, default=-1, help="PT_OPT_PACKET (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_MAX_PATHS, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_MAX_PATHS, PT_OPT_PACKET, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -125,6 +126,8 @@ def main():
         r.set_option(PT_OPT_ROLLING, args.rolling)
     if args.live_factor:
         r.set_option(PT_OPT_LIVE_FACTOR, args.live_factor)
+    if args.packet >= 0:
+        r.set_option(PT_OPT_PACKET, args.packet)
     if args.integrator == "nee":
         r.set_option(PT_OPT_INTEGRATOR, 1)
     if args.bsdf_probability != 1.0:
@@ -234,9 +237,10 @@ def main():
                        "integrator": args.integrator, "bsdf_sample_probability": args.bsdf_probability,
                        "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
                                     "library default (rolling, one pipe, up to 24 M paths started per launch)" if args.rolling < 0 else "one batch at a time per pipe")},
-            "roofline": {"bound": "hbm", "kernel": "k_extend_walk", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_extend_walk + k_extend_packet (one step's closest-hit search: queued rays and new paths, side by side)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "hbm_counter_frac": hbm_counter_frac, "valu_issue_frac": valu_issue_frac, "lane_util": lane_util,
+                         "counters_from": "profiles/r02_counters.json: rocprofv3 --pmc passes of this command, recorded (per-ray figures scaled by this run's rays and launch time)" if traffic is not None else None,
                          "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
                          "launches": st["extend_launches"], "busy_ms": st["extend_busy_ms"],
                          "achieved_over_union_of_launches": union_busy,

@@ -122,7 +122,8 @@ impl FlatScene {
     }
 
     /// One PrimitiveBuffer; `may_hold_instances` is false for the children of instances and for lights
-    /// (instances inside instances are refused by the library, lights that are instances have pdf 0).
+    /// (the library takes one level of instancing, which is what the reference's scenes use; deeper nesting would
+    /// have to be lifted here, transforms composed, as libpthost does; lights that are instances have pdf 0).
     fn add_set(&mut self, p: &PrimitiveBuffer, may_hold_instances: bool) -> pt_primset_desc {
         let mut set = pt_primset_desc::default();
         let first = self.tri_mat.len();

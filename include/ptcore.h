@@ -187,6 +187,11 @@ enum {
                                            by BSDF sampling, balance heuristic between the two; BSDF_SAMPLE_PROBABILITY
                                            is not used */
     PT_OPT_TAIL_BELOW = 9,              /* accepted and ignored (it selected a launch that no longer exists) */
+    PT_OPT_PACKET = 14,                 /* 1 (default): the paths that start with a launch (camera rays: 64 consecutive ones are
+                                           a few neighbouring pixels with all their strata) are searched a wave at a time,
+                                           the wave walking the reference's loop once with a lane mask, nodes and triangles
+                                           read once per wave; worlds without an instance buffer only.  0: every ray on
+                                           its own, as the rays of later bounces always are.  Same results either way */
     PT_OPT_LIVE_FACTOR = 13             /* rolling schedule: rays in flight a pipe has room for, as a multiple of the paths
                                            started per launch (at least 2, at most max_depth; default 4).  A batch starts
                                            only when its paths fit beside the rays in flight, so a scene whose paths live

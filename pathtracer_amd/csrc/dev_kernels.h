@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dev_packet.h"
 #include "dev_shade.h"
 #include "dev_walk.h"
 
@@ -341,6 +342,51 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
                 classify(sc, ps, wl, background, done, pos, h.code, h.prim);
             }
         });
+    shade_push_close(ps);
+}
+
+// PrimitiveBuffer::hit for the paths that start with this step, 64 consecutive slots per wave: a few neighbouring
+// pixels with all the strata of the batch, rays that differ by a fraction of a pixel.  The wave searches for
+// all of them at once (dev_packet.h); each lane's own sequence of tests is the reference's.  For worlds without
+// an instance buffer whose BVHs have reference-order nodes; the rays queued by earlier steps go through
+// k_extend_walk, launched beside this kernel with no fresh paths of its own.
+template <bool MOVING>
+__global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
+    const WorkList wl = work_list(ps, bounce, fp);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && fp.n_new) {
+        if (wl.queued == 0u) atomicAdd(&stats->extend_nonempty, 1ull);  // else k_extend_walk counts the step
+        atomicAdd(&stats->paths_total, (unsigned long long)fp.n_new);
+        atomicAdd(&stats->rays_total, (unsigned long long)fp.n_new);
+    }
+    shade_push_init();
+    const uint32_t n_pieces = (fp.n_new + 63u) / 64u;
+    for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
+        const uint32_t i = piece * 64u + lane_id();
+        const bool active = i < fp.n_new;
+        const uint32_t pos = wl.queued + i;
+        HitState h;
+        h.code = PTD_HIT_MISS;
+        h.u = h.v = 0.0f;
+        h.prim = 0u;
+        f3 o = mk3(0.0f, 0.0f, 0.0f), d = mk3(1.0f, 1.0f, 1.0f);
+        float time = 0.0f;
+        if (active) {
+            uint32_t draws;
+            fresh_path(cam, ps, fp.new_base + i, o, d, draws, time);
+        }
+        TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
+        const bool plain = sc.boxes_finite != 0u && __ballot(active && !ray_is_plain(r)) == 0ull;
+        packet_hit_world(sc, __ballot(active), plain, r, h);
+        if (active) {
+            if constexpr (MOVING) {
+                TravCounters tc{0, 0, 0, 0};
+                hit_moving_spheres(sc, time, r, h, tc);
+            }
+            ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+            ps.hit2[pos] = h.code;
+        }
+        classify(sc, ps, wl, background, active, pos, h.code, h.prim);
+    }
     shade_push_close(ps);
 }
 
@@ -681,6 +727,81 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_walk(DevScene sc, PathState ps
             const f3 add = cmul(mk3(f.x, f.y, f.z), e);
             ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
         });
+}
+
+// Paths of one batch that are still alive when the batch is due: each lane takes such a path out of the ray
+// queue the step's shading has just filled and alternates closest hit (the reference-order loop) and
+// shade_vertex until the path ends.  This happens under light sampling only: a vertex that samples a light
+// resets the depth left to 2 (src/camera.rs:332), so a path that keeps doing that outlives max_depth, which
+// is all the schedules plan for.  `region`: the batch's region of the slot arrays.  The path's state stays
+// where its ray's queue entry was (position `pos` of the arrays of the next step's parity, and of the hit
+// arrays, which the finished step no longer needs); the queue entry becomes padding.
+template <bool MEDIA>
+__global__ __launch_bounds__(BLOCK) void k_finish(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, uint32_t region, f3 background,
+                                                  DevStats *stats) {
+    const uint32_t np = (bounce & 1u) ^ 1u;
+    const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + np) * CTL_STRIDE], ps.max_ray_chunks);
+    uint32_t *queue = ps.ray_queue[np];
+    const WorkList wl{np, 0xFFFFFFFFu, FreshPaths{0u, 0u}};  // every position is a queue position
+    LaneStack st;
+    st.init(ps.overflow, ps.overflow_stride);
+    TravCounters tc{0, 0, 0, 0};
+    const bool insts = sc.world.insts.prim_count != 0u;
+    uint32_t traced = 0u;  // rays beyond the queued ones (those are already counted)
+    const uint32_t n_pos = n_chunks * QUEUE_CHUNK;
+    for (uint32_t pos = blockIdx.x * BLOCK + threadIdx.x; pos < n_pos; pos += gridDim.x * BLOCK) {
+        const uint32_t slot = queue[pos];
+        if (slot == QUEUE_EMPTY || slot / ps.region_cap != region) continue;
+        queue[pos] = QUEUE_EMPTY;
+        for (bool first = true;; first = false) {
+            if (!first) traced++;
+            const float4 ro = ps.ray_o[np][pos], rd = ps.ray_d[np][pos];
+            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            HitState h;
+            hit_world_prims(sc, r, h, st, tc);
+            if (insts) hit_world_insts(sc, r, h, st, tc);
+            if (sc.n_moving != 0u) hit_moving_spheres(sc, ps.beta[np][pos].w, r, h, tc);
+            int32_t mat = -1;
+            if (h.code != PTD_HIT_MISS) {
+                const uint32_t type = h.code & 3u;
+                mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
+            }
+            ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+            ps.hit2[pos] = h.code;
+            VertexOut v;
+            v.alive = v.shadow = false;
+            if (mat < 0) {
+                if constexpr (MEDIA) {
+                    shade_vertex<PTD_MAT_MEDIUM, false, true>(sc, cam, ps, bp, wl, pos, slot, v);
+                } else {  // src/camera.rs:371, :277-283
+                    const float4 b = ps.beta[np][pos];
+                    const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
+                    ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+                }
+            } else {
+                switch (sc.mats[mat].type) {
+#define FINISH(MT) case MT: shade_vertex<MT, false, MEDIA>(sc, cam, ps, bp, wl, pos, slot, v); break;
+                    FINISH(PTS_MAT_LAMBERTIAN)
+                    FINISH(PTS_MAT_METAL)
+                    FINISH(PTS_MAT_DIELECTRIC)
+                    FINISH(PTS_MAT_DIFFUSE_LIGHT)
+                    FINISH(PTS_MAT_DISNEY)
+                    FINISH(PTS_MAT_DISNEY_DIFFUSE)
+                    FINISH(PTS_MAT_DISNEY_METAL)
+                    FINISH(PTS_MAT_DISNEY_GLASS)
+                    FINISH(PTS_MAT_DISNEY_CLEARCOAT)
+                    FINISH(PTS_MAT_DISNEY_SHEEN)
+#undef FINISH
+                    default: break;
+                }
+            }
+            if (!v.alive) break;
+            ps.ray_o[np][pos] = v.ray_o;
+            ps.ray_d[np][pos] = v.ray_d;
+            ps.beta[np][pos] = v.beta;
+        }
+    }
+    if (traced) atomicAdd(&stats->rays_total, (unsigned long long)traced);
 }
 
 // `*pixel += pixel_color` once per stratum, in stratum order, NaN samples skipped (camera.rs:212-217).  The

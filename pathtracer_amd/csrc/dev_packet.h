@@ -1,0 +1,130 @@
+// Closest-hit search for a wave whose 64 rays are nearly the same ray (camera rays of neighbouring
+// pixels and strata): the reference's loop (InnerPrimitiveBuffer::traverse, src/bvh.rs:725-797) run once
+// per WAVE over the 32-byte reference-order nodes, with a lane mask saying whose loop is at this node.
+//
+// Every lane's own sequence of box and primitive tests is exactly the sequence traverse() in
+// dev_traverse.h performs for its ray, each test with that lane's t_max of the moment:
+//   - a node is visited with the mask M of the lanes whose loop would visit it now; each of them tests
+//     the node's box itself (the reference tests a box when it visits the node, never earlier);
+//   - at an interior node the lanes that passed go on to the child their own direction makes the near
+//     one.  When they all agree the far child is stacked with the same mask.  When they do not (A: left
+//     first, B: right first) the wave visits left with A, then right with A and B, then left with B:
+//     each lane still sees its two children in its own order, and what the wave does in between does
+//     not touch it;
+//   - at a leaf the lanes that passed test its primitives in order.
+// Nodes and primitives are the same for all lanes, so they are read through the constant address space
+// (scalar loads, one per wave), and the stack holds one (node, mask) pair per entry for the whole wave.
+#pragma once
+#include "dev_traverse.h"
+
+namespace ptd {
+
+// stack entries per wave: two per level in the worst case (lanes that disagree about the near child),
+// trees are at most 64 levels deep (checked at upload)
+constexpr int PACKET_LEVELS = 2 * 64 + 8;
+__shared__ uint32_t g_packet_stack[BLOCK / 64][PACKET_LEVELS][3];
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// A pointer to memory that nothing writes while the scene lives, whose loads at a wave-uniform address go over
+// the scalar unit (constant address space): one load per wave, the values arrive in scalar registers.
+// (The alternative, one coalesced vector load per wave with lane k fetching dword k and v_readlane to spread
+// the values, was measured slower: 0.099 ns per camera ray against 0.087, one ray per lane taking 0.106.)
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct ScalarF4 {
+    const __attribute__((address_space(4))) v4f *p;
+    __device__ __forceinline__ float4 operator[](uint32_t i) const {
+        const v4f v = p[i];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+};
+__device__ __forceinline__ ScalarF4 scalar_f4(const float4 *q) { return ScalarF4{(const __attribute__((address_space(4))) v4f *)q}; }
+
+// leaf(g, on): primitive g (the same in every lane) for the lanes with on == true.
+// `plain`: no lane of the wave can produce a NaN in the box test (ray_is_plain), finite boxes.
+template <class LeafFn>
+__device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuffer &buf, unsigned long long active, bool plain, TravRay &r,
+                                                LeafFn &&leaf) {
+    if (buf.prim_count == 0u || active == 0ull) return;
+    const unsigned long long lane_bit = 1ull << lane_id();
+    if (buf.node_count == 0u) {  // no BVH: src/bvh.rs:726-737
+#pragma unroll 1
+        for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i, (active & lane_bit) != 0ull);
+        return;
+    }
+    const ScalarF4 nodes = scalar_f4(sc.nodes + 2 * (size_t)buf.node_first);
+    uint32_t(*stack)[3] = g_packet_stack[threadIdx.x / 64u];
+    int sp = 0;
+    uint32_t cur = 0u;
+    unsigned long long mask = active;
+    for (;;) {
+        const float4 n0 = nodes[2u * cur], n1 = nodes[2u * cur + 1u];
+        bool hit = (mask & lane_bit) != 0ull;
+        if (hit) {
+            float e;
+            hit = plain ? slab_test_entry_plain(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, e) : slab_test(n0, n1, r);
+        }
+        const unsigned long long passed = __ballot(hit);
+        bool descend = false;
+        if (passed != 0ull) {
+            const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
+            if (!(b & PT_NODE_LEAF)) {
+                const float da = (b == 0u) ? r.d.x : ((b == 1u) ? r.d.y : r.d.z);
+                const unsigned long long right_first = __ballot(hit && da < 0.0f), left_first = passed & ~right_first;
+                auto push = [&](uint32_t node, unsigned long long m) {
+                    if (lane_id() == 0u) {
+                        stack[sp][0] = node;
+                        stack[sp][1] = (uint32_t)m;
+                        stack[sp][2] = (uint32_t)(m >> 32);
+                    }
+                    sp++;
+                };
+                if (right_first == 0ull) {
+                    push(a, left_first);
+                    cur = cur + 1u;
+                    mask = left_first;
+                } else if (left_first == 0ull) {
+                    push(cur + 1u, right_first);
+                    cur = a;
+                    mask = right_first;
+                } else {
+                    push(cur + 1u, right_first);
+                    push(a, passed);
+                    cur = cur + 1u;
+                    mask = left_first;
+                }
+                descend = true;
+            } else {
+                const uint32_t cnt = b & 0xFFFFu;
+#pragma unroll 1
+                for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i, hit);
+            }
+        }
+        if (!descend) {
+            if (sp == 0) break;
+            sp--;
+            cur = uniform(stack[sp][0]);
+            mask = (unsigned long long)uniform(stack[sp][1]) | ((unsigned long long)uniform(stack[sp][2]) << 32);
+        }
+    }
+}
+
+// The triangle, sphere and quad buffers of the world, in that order (PrimitiveBuffer::hit, src/objects.rs:192-194),
+// for a wave of rays; lanes outside `active` have no ray.
+__device__ __forceinline__ void packet_hit_world(const DevScene &sc, unsigned long long active, bool plain, TravRay &r, HitState &h) {
+    const ScalarF4 tri_hot = scalar_f4(sc.tri_hot), spheres = scalar_f4(sc.spheres), quads = scalar_f4(sc.quads);
+    packet_traverse(sc, sc.world.tris, active, plain, r, [&](uint32_t g, bool on) {
+        const float4 a = tri_hot[3u * g], b = tri_hot[3u * g + 1u], c = tri_hot[3u * g + 2u];
+        if (on) hit_tri(a, b, c, g, r, h, 0u);
+    });
+    packet_traverse(sc, sc.world.spheres, active, plain, r, [&](uint32_t g, bool on) {
+        const float4 s = spheres[g];
+        if (on) hit_sphere(s, g, r, h, 0u);
+    });
+    packet_traverse(sc, sc.world.quads, active, plain, r, [&](uint32_t g, bool on) {
+        const float4 q0 = quads[4u * g], q1 = quads[4u * g + 1u], q2 = quads[4u * g + 2u], q3 = quads[4u * g + 3u];
+        if (on) hit_quad(q0, q1, q2, q3, g, r, h, 0u);
+    });
+}
+
+}  // namespace ptd

@@ -187,11 +187,8 @@ template <int TYPE>
 __device__ __forceinline__ void hit_prim(const DevScene &sc, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code,
                                          TravCounters &tc);
 
-template <>
-__device__ __forceinline__ void hit_prim<PT_PRIM_TRI>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
-                                                      uint32_t inst_code, TravCounters &tc) {
-    tc.tris++;
-    const float4 a = sc.tri_hot[3 * g], b = sc.tri_hot[3 * g + 1], c = sc.tri_hot[3 * g + 2];
+// Triangle::hit (src/objects/tri_mesh.rs:167-198) on the three float4 of tri_hot: v0, e1, e2.
+__device__ __forceinline__ void hit_tri(float4 a, float4 b, float4 c, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code) {
     f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
     f3 e1_x_d = cross(e1, r.d);
     float triple = dot(e1_x_d, e2);
@@ -210,6 +207,12 @@ __device__ __forceinline__ void hit_prim<PT_PRIM_TRI>(const DevScene &sc, uint32
     h.v = v;
     h.prim = g;
     h.code = PT_PRIM_TRI | inst_code;
+}
+template <>
+__device__ __forceinline__ void hit_prim<PT_PRIM_TRI>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
+                                                      uint32_t inst_code, TravCounters &tc) {
+    tc.tris++;
+    hit_tri(sc.tri_hot[3 * g], sc.tri_hot[3 * g + 1], sc.tri_hot[3 * g + 2], g, r, h, inst_code);
 }
 
 // Sphere::hit (src/objects/sphere.rs:56-99) for sphere g with its centre and radius in s.
@@ -240,11 +243,8 @@ __device__ __forceinline__ void hit_sphere(float4 s, uint32_t g, TravRay &r, Hit
     h.code = PT_PRIM_SPHERE | inst_code;
 }
 
-template <>
-__device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
-                                                       uint32_t inst_code, TravCounters &tc) {
-    tc.quads++;
-    const float4 q0 = sc.quads[4 * g], q1 = sc.quads[4 * g + 1], q2 = sc.quads[4 * g + 2], q3 = sc.quads[4 * g + 3];
+// Quad::hit (src/objects/quad_mesh.rs:126-147) on the four float4 of `quads`.
+__device__ __forceinline__ void hit_quad(float4 q0, float4 q1, float4 q2, float4 q3, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code) {
     f3 origin = mk3(q0.x, q0.y, q0.z), qu = mk3(q0.w, q1.x, q1.y), qv = mk3(q1.z, q1.w, q2.x);
     f3 normal = mk3(q2.y, q2.z, q2.w), w = mk3(q3.x, q3.y, q3.z);
     float d = q3.w;
@@ -262,6 +262,12 @@ __device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint3
     h.v = beta;
     h.prim = g;
     h.code = PT_PRIM_QUAD | inst_code;
+}
+template <>
+__device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
+                                                       uint32_t inst_code, TravCounters &tc) {
+    tc.quads++;
+    hit_quad(sc.quads[4 * g], sc.quads[4 * g + 1], sc.quads[4 * g + 2], sc.quads[4 * g + 3], g, r, h, inst_code);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -48,6 +48,10 @@ struct pt_context {
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
+    // The paths that start with a step are searched a wave at a time (k_extend_packet): worlds without an instance
+    // buffer whose BVHs come with reference-order nodes (packet_ok, decided at upload).
+    bool packet_ok = false, packet = true;  // PT_OPT_PACKET
+    bool use_packet() const { return packet && packet_ok && use_wide() && !counters; }
 #ifdef PT_WALK_WAVES
     int blocks_per_cu = PT_WALK_WAVES;
 #else
@@ -485,6 +489,11 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_TAIL_BELOW:  // kept for callers that set it: the launch it switched on is gone
             if (!(value >= 0.0 && value <= 1.0e9)) return fail(ctx, PT_ERR_INVALID, "tail threshold out of range");
             return PT_OK;
+        case PT_OPT_PACKET:
+            if (value != 0.0 && value != 1.0) return fail(ctx, PT_ERR_INVALID, "packet option must be 0 or 1");
+            sync_pipes(ctx);
+            ctx->packet = value != 0.0;
+            return PT_OK;
         case PT_OPT_LIVE_FACTOR:
             if (!(value >= 2.0 && value <= 1.0e6)) return fail(ctx, PT_ERR_INVALID, "live factor must be at least 2");
             ctx->live_factor = value;
@@ -813,6 +822,8 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         // + the newest entry kept in registers, + the two records an instance descent leaves on the stack
         ctx->stack_need = std::max(set_depth(0), depth_of[0][3] + child_depth) + 4u;
         ctx->wide_ok = wide_ok;
+        const DevSet &w = sets[0];
+        ctx->packet_ok = w.insts.prim_count == 0u && w.tris.tree != 2u && w.spheres.tree != 2u && w.quads.tree != 2u;
     }
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->quad_mat, s->n_quads))) return rc;
     d.quad_mat = pi;
@@ -1089,7 +1100,9 @@ static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
 
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
 // fp: the paths that start with this step (on their camera rays; nothing is stored for them).
-static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, FreshPaths fp) {
+// side, fork, join: a second stream of the pipe with two events (or null): where k_extend_packet runs.
+static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, FreshPaths fp, hipStream_t side = nullptr,
+                          hipEvent_t fork = nullptr, hipEvent_t join = nullptr) {
     const dim3 g(grid), b(BLOCK);
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
@@ -1098,13 +1111,25 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
     if (ctx->counters) {
         if (insts) { EXT(true, false); EXI(true); } else EXT(true, true);
     } else if (ctx->use_wide()) {
-#define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
+        FreshPaths walk_fp = fp;
+        if (ctx->use_packet() && fp.n_new != 0u && side != nullptr) {
+            // the new paths a wave at a time, beside the rays queued by earlier steps
+            (void)hipEventRecord(fork, st);
+            (void)hipStreamWaitEvent(side, fork, 0);
+            const dim3 gp((unsigned)std::min<uint64_t>(((uint64_t)fp.n_new + BLOCK - 1) / BLOCK, (uint64_t)ctx->n_cu * 8u));
+            if (ctx->scene.n_moving != 0) hipLaunchKernelGGL((k_extend_packet<true>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats);
+            else hipLaunchKernelGGL((k_extend_packet<false>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats);
+            (void)hipEventRecord(join, side);
+            walk_fp.n_new = 0u;
+        }
+#define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, walk_fp, ctx->stats)
         if (ctx->scene.n_moving != 0) {
             if (insts) EXW(true, true); else EXW(false, true);
         } else {
             if (insts) EXW(true, false); else EXW(false, false);
         }
 #undef EXW
+        if (walk_fp.n_new != fp.n_new) (void)hipStreamWaitEvent(st, join, 0);
     } else {
         if (insts) { EXT(false, false); EXI(false); } else EXT(false, true);
     }
@@ -1171,6 +1196,15 @@ static void launch_shade_type(int type, const ShadeLaunch &l) {
         case PTS_MAT_DISNEY_SHEEN: launch_shade<PTS_MAT_DISNEY_SHEEN>(l); break;
         case PTD_MAT_MEDIUM: launch_shade<PTD_MAT_MEDIUM>(l); break;
     }
+}
+
+// Under light sampling a path can outlive max_depth (a vertex that samples a light resets the depth left to 2,
+// src/camera.rs:332): what is left of a batch when it is due is finished by k_finish.
+static bool paths_may_outlive_depth(const pt_context *ctx) { return !ctx->nee && ctx->bsdf_prob < 1.0f; }
+static void launch_finish(pt_context *ctx, hipStream_t st, const PathState &ps, const BatchParams &bp, uint32_t bounce, uint32_t region) {
+    const dim3 g(grid_fixed(ctx, ~0ull >> 1)), b(BLOCK);
+    if (ctx->scene.n_media != 0) hipLaunchKernelGGL((k_finish<true>), g, b, 0, st, ctx->scene, ctx->cam, ps, bp, bounce, region, ctx->cam.background, ctx->stats);
+    else hipLaunchKernelGGL((k_finish<false>), g, b, 0, st, ctx->scene, ctx->cam, ps, bp, bounce, region, ctx->cam.background, ctx->stats);
 }
 
 static uint64_t mix64_host(uint64_t z) {
@@ -1257,12 +1291,13 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
             g_sh = std::min(grid_shade, (want + 7) / 8 * 8);
         }
         const FreshPaths fp{0u, b == 0u ? (uint32_t)n_slots : 0u};  // every path of the batch starts with its first step
-        launch_extend(ctx, st, g_ext, ps, b, fp);
+        launch_extend(ctx, st, g_ext, ps, b, fp, pp.side[0], pp.fork, pp.join[0]);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
         if ((rc = launch_shades(ctx, pp, ShadeLaunch{ctx, st, &ps, g_sh, &bp, b, 0u, fp}))) return rc;
         if (ctx->nee) launch_shadow(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
+    if (paths_may_outlive_depth(ctx)) launch_finish(ctx, st, ps, bp, depth - 1u, 0u);
     if (bounces_out) *bounces_out = bounces;
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1382,7 +1417,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
     hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(1), 0, st, ps.regions, region, rp, nb ? 1u : 0u, ps.next_rays);
     if (prof) (void)hipEventRecord(r.prof[ring][1], st);
     const uint64_t bound = r.n_live + r.cap;
-    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp);
+    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp, pp.side[0], pp.fork, pp.join[0]);
     if (prof) (void)hipEventRecord(r.prof[ring][2], st);
     BatchParams common{};
     common.npix = ctx->cam.width * ctx->cam.height;
@@ -1400,6 +1435,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
         // in stratum order over all pipes: ticks go round the pipes, so batches fall due in the order they started
         const pt_context::Due d = r.due.front();
         r.due.pop_front();
+        if (paths_may_outlive_depth(ctx)) launch_finish(ctx, st, ps, common, parity, d.region);
         if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_accumulated, 0));
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, common.npix)), dim3(BLOCK), 0, st, ps.contrib + (size_t)d.region * r.cap, ctx->accum, common.npix,
                            d.n_strata);

@@ -190,3 +190,37 @@ def test_new_option_ranges_are_checked():
     for key, bad in ((PT_OPT_ROLLING, -1), (PT_OPT_TAIL_BELOW, -1), (PT_OPT_LIVE_FACTOR, 1.5), (PT_OPT_INTEGRATOR, 2), (PT_OPT_INTEGRATOR, 0.5), (PT_OPT_DEVICE_BVH, -3)):
         with pytest.raises(PtError):
             r.set_option(key, bad)
+
+
+def _packet_scenes():
+    from tests.test_motion import _scene as moving
+    # worlds without an instance buffer: triangles in a BVH, spheres and quads with and without one, a lens,
+    # an image narrower than a wave, moving spheres
+    yield "knob", scenes.knob(width=80, spp=36, max_depth=12, detail=0.2)
+    yield "interior", scenes.interior(width=96, spp=36, max_depth=8, n_lights=9, columns=3)
+    yield "lucy", scenes.lucy(width=72, spp=36, max_depth=8, detail=0.1)
+    yield "moving", moving((-2.0, 0.0, 0.0), (2.0, 0.5, 0.0), width=40, spp=36, depth=6, extras=True)
+    yield "one_row", scenes.knob(width=7, spp=36, max_depth=5, detail=0.1)
+
+
+@pytest.mark.parametrize("name", ["knob", "interior", "lucy", "moving", "one_row"])
+def test_camera_rays_searched_a_wave_at_a_time_give_the_same_bits(name):
+    # PT_OPT_PACKET: per-sample radiance (one batch at a time) and the accumulator (rolling schedule) with and without
+    from pathtracer_amd.core import PT_OPT_PACKET, PT_OPT_ROLLING
+    src = dict(_packet_scenes())[name]
+    got = []
+    for packet in (0, 1):
+        r = _renderer(src)
+        r.set_option(PT_OPT_PACKET, packet)
+        samples = r.render_samples(0, 5, seed=3)
+        r.render(0, 20, seed=7)
+        r.render(20, 36, seed=7)
+        acc, n = r.read_accum()
+        assert n == 36
+        r.set_option(PT_OPT_ROLLING, 0)
+        r.reset_accum()
+        r.render(0, 36, seed=7)
+        got.append((samples, acc, r.read_accum()[0]))
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(got[1][1].view(np.uint32), got[1][2].view(np.uint32))  # both schedules, packets on

@@ -238,3 +238,34 @@ def test_vertices_inside_a_sphere_light_poison_their_paths_as_in_the_reference()
     close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
     assert close.mean() > 0.995, close.mean()
     assert ref.sum() > 0
+
+
+@pytest.mark.parametrize("name,depth,prob", [("cornell", 3, 0.5), ("small_mixed", 2, 0.25), ("cornell", 1, 0.5)])
+def test_paths_that_outlive_max_depth_under_light_sampling(name, depth, prob):
+    """A vertex that samples a light resets the depth left to 2 (src/camera.rs:332), so with a small max_depth and
+    BSDF_SAMPLE_PROBABILITY < 1 many paths go on beyond max_depth bounces.  The recursion of the reference follows
+    them; so must the device, in both schedules, with the same bits in both and from run to run."""
+    from pathtracer_amd.core import PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_ROLLING
+    src = {"cornell": lambda: scenes.cornell(48, 36, max_depth=depth), "small_mixed": lambda: scenes.small_mixed(48, 36, max_depth=depth)}[name]()
+    o, r = _pair(src)
+    o.set_bsdf_probability(prob)
+    r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, prob)
+    ref = np.nan_to_num(o.render(0, 6, seed=13, iterative=False, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 6, seed=13), nan=0.0, posinf=0.0, neginf=0.0)
+    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
+    assert close.mean() > 0.99, close.mean()
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
+    accs = []
+    rays = []
+    for rolling in (0, 48 * 48 * 5, 48 * 48 * 5, 1 << 22):
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.reset_accum()
+        r.stats_reset()
+        r.render(0, 20, seed=5)
+        r.render(20, 36, seed=5)
+        accs.append(r.read_accum()[0].copy())
+        rays.append(r.stats()["rays"])
+    assert rays[0] == rays[1] == rays[2] == rays[3], rays
+    assert rays[0] > (depth + 0.5) * 36 * 48 * 48 * 0.2  # many paths are longer than max_depth
+    for a in accs[1:]:
+        assert np.array_equal(a.view(np.uint32), accs[0].view(np.uint32))

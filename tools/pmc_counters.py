@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-ray hardware-counter figures of the closest-hit kernel from the passes of tools/pmc_passes.sh.
+"""Per-ray hardware-counter figures of the closest-hit kernels (summed over both) from the passes of tools/pmc_passes.sh.
 
 Every pass is one rocprofv3 --pmc run of the same short bench.py command (kernels run one at a time
 under the counters); the bench line in each pass's log gives the rays that run traced.  Output: one
@@ -19,7 +19,7 @@ import sys
 from collections import defaultdict
 
 root, out = sys.argv[1], sys.argv[2]
-kernel = "k_extend_walk"
+kernels = ("k_extend_walk", "k_extend_packet")  # the two closest-hit kernels of a step: queued rays, new paths
 PASSES = ("sq_time", "sq_insts", "cache", "fetch", "write")
 
 
@@ -36,7 +36,7 @@ def totals(name):
     dur = {}
     with open(os.path.join(root, name, f"{name}_counter_collection.csv"), newline="") as f:
         for r in csv.DictReader(f):
-            if kernel in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in kernels):
                 tot[r["Counter_Name"]] += float(r["Counter_Value"])
                 dur[int(r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return tot, len(dur), sum(dur.values()) * 1e-9
@@ -69,7 +69,7 @@ def ratio(a, b):
 
 b0 = lines["sq_time"]
 res = {
-    "kernel": kernel,
+    "kernel": " + ".join(kernels),
     "command": "bench.py " + " ".join(sys.argv[3:]) + " under rocprofv3 --pmc, one run per pass (tools/pmc_passes.sh)",
     "workload": b0["config"]["workload"],
     "dispatches": disp["sq_time"],
