@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--extensions", action="store_true", help="next_week_like with its noise texture, media and moving sphere")
     ap.add_argument("--max-depth", type=int, default=0, help="knob: override the scene's depth of 50 (experiments only)")
     ap.add_argument("--packet", type=int, default=-1, help="PT_OPT_PACKET (-1: library default)")
+    ap.add_argument("--batch-ticks", type=int, default=-1, help="PT_OPT_BATCH_TICKS (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -92,7 +93,7 @@ def main():
     import torch.distributed as dist
 
     from pathtracer_amd import scenes
-    from pathtracer_amd.core import (PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_MAX_PATHS, PT_OPT_PACKET, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
+    from pathtracer_amd.core import (PT_OPT_BATCH_TICKS, PT_OPT_BLOCKS_PER_CU, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_COUNTERS, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_INTEGRATOR, PT_OPT_LEAF_BATCH, PT_OPT_LIVE_FACTOR, PT_OPT_MAX_PATHS, PT_OPT_PACKET, PT_OPT_PIPES, PT_OPT_PROFILE, PT_OPT_REFILL_BELOW,
                                      HostScene, Renderer)
     from pathtracer_amd.sharding import reduce_accumulator, stratum_ranges
 
@@ -128,6 +129,8 @@ def main():
         r.set_option(PT_OPT_LIVE_FACTOR, args.live_factor)
     if args.packet >= 0:
         r.set_option(PT_OPT_PACKET, args.packet)
+    if args.batch_ticks >= 0:
+        r.set_option(PT_OPT_BATCH_TICKS, args.batch_ticks)
     if args.integrator == "nee":
         r.set_option(PT_OPT_INTEGRATOR, 1)
     if args.bsdf_probability != 1.0:

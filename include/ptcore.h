@@ -192,6 +192,12 @@ enum {
                                            the wave walking the reference's loop once with a lane mask, nodes and triangles
                                            read once per wave; worlds without an instance buffer only.  0: every ray on
                                            its own, as the rays of later bounces always are.  Same results either way */
+    PT_OPT_BATCH_TICKS = 15,            /* rolling schedule: launches a batch takes part in before the few paths it still has are
+                                           finished in one go; its per-path sums are held that long, so this sets the
+                                           memory (16 B x paths per launch x this).  0 (default): max_depth at first, then
+                                           what the first drain of the pipeline shows about how fast this scene's paths
+                                           end (a handful of paths left, at least 8 launches); 1: always
+                                           max_depth; >= 2: that many.  Same results for any value */
     PT_OPT_LIVE_FACTOR = 13             /* rolling schedule: rays in flight a pipe has room for, as a multiple of the paths
                                            started per launch (at least 2, at most max_depth; default 4).  A batch starts
                                            only when its paths fit beside the rays in flight, so a scene whose paths live

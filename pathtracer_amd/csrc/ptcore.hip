@@ -61,7 +61,16 @@ struct pt_context {
     bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
     uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
     double live_factor = 4.0;  // PT_OPT_LIVE_FACTOR
-    bool shade_spread = getenv("PT_SHADE_SPREAD") ? atoi(getenv("PT_SHADE_SPREAD")) != 0 : true;
+    // PT_OPT_BATCH_TICKS: launches a batch of the rolling schedule takes part in before what is left of it is
+    // finished in one go (k_finish); its slots are held that long.  0: max_depth launches.
+    uint32_t batch_ticks = 0;  // 0: learnt from the scene (auto_ticks, once a drain has been seen), 1: max_depth
+    uint32_t auto_ticks = 0;   // 0: not known yet
+    uint32_t roll_regions() const {
+        if (nee) return cam.max_depth;  // k_finish knows the reference's estimator only
+        const uint32_t want = batch_ticks >= 2u ? batch_ticks : (batch_ticks == 0u && auto_ticks != 0u ? auto_ticks : cam.max_depth);
+        return want < cam.max_depth ? want : cam.max_depth;
+    }
+    bool shade_spread = true;  // the shading launches of a step on several streams
 
     // scene
     bool have_scene = false, have_camera = false;
@@ -126,6 +135,11 @@ struct pt_context {
         uint32_t ring_new[ROLL_RING] = {};
         uint64_t counted = 0;
         uint32_t known_rays = 0;
+        // How fast this scene's paths end: drain_rays[j] = rays still queued after tick last_start + j, where
+        // last_start is the last tick that started a batch (so nothing but survivors is counted).
+        uint64_t last_start = 0;
+        bool any_start = false;
+        std::vector<uint32_t> drain_rays;
         std::deque<Due> due;
         hipEvent_t done[ROLL_RING] = {}, accumulated[ROLL_RING] = {};
         hipEvent_t prof[ROLL_RING][4] = {};  // before raygen, before extend, after extend, after shading
@@ -279,6 +293,8 @@ static void destroy_pipes(pt_context *ctx) {
     ctx->epoch = nullptr;
 }
 static int roll_flush(pt_context *ctx);
+static uint32_t roll_learn(pt_context *ctx);
+static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &r, uint32_t n_regions, uint32_t cap, uint64_t n_live);
 // Waits for everything enqueued (finish_batches: after enqueueing what the batches under way still need).
 static void sync_pipes(pt_context *ctx, bool finish_batches = true) {
     if (finish_batches) (void)roll_flush(ctx);
@@ -322,6 +338,19 @@ static int sync_all(pt_context *ctx) {
         ctx->extend_iv.clear();
     }
     HIP_TRY(ctx, hipGetLastError());
+    if (ctx->batch_ticks == 0u) {
+        // what the drain has shown about this scene's paths; the slot arrays change size now, while nothing is under way
+        const uint32_t learnt = roll_learn(ctx);
+        if (learnt != 0u && (ctx->auto_ticks == 0u || learnt > ctx->auto_ticks || learnt + 4u <= ctx->auto_ticks)) {
+            ctx->auto_ticks = learnt;
+            const uint32_t regions = ctx->roll_regions();
+            for (int p = 0; p < ctx->n_roll_pipes; p++) {
+                pt_context::Roll &r = ctx->rolls[p];
+                if (r.cap != 0u && r.n_regions != regions)
+                    if (int rc = ensure_roll(ctx, ctx->pipes[p], r, regions, r.cap, r.n_live)) return rc;
+            }
+        }
+    }
     {
         unsigned long long dropped = 0;
         HIP_TRY(ctx, hipMemcpy(&dropped, &ctx->stats->queue_overflow, sizeof dropped, hipMemcpyDeviceToHost));
@@ -434,6 +463,7 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_BSDF_SAMPLE_PROBABILITY:
             if (!(value >= 0.0 && value <= 1.0)) return fail(ctx, PT_ERR_INVALID, "bsdf sample probability must be in [0,1]");
             ctx->bsdf_prob = (float)value;
+            ctx->auto_ticks = 0;  // paths end at another rate
             forget_bounce_profile(ctx);
             return PT_OK;
         case PT_OPT_MAX_PATHS:
@@ -471,6 +501,7 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_INTEGRATOR:
             if (value != 0.0 && value != 1.0) return fail(ctx, PT_ERR_INVALID, "integrator must be 0 (the reference's) or 1 (next-event estimation)");
             ctx->nee = value != 0.0;
+            ctx->auto_ticks = 0;
             for (auto &pp : ctx->pipes) {  // the shadow-ray queue exists only with next-event estimation
                 free_pool(ctx, pp.allocs);
                 pp.capacity = 0;
@@ -493,6 +524,10 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             if (value != 0.0 && value != 1.0) return fail(ctx, PT_ERR_INVALID, "packet option must be 0 or 1");
             sync_pipes(ctx);
             ctx->packet = value != 0.0;
+            return PT_OK;
+        case PT_OPT_BATCH_TICKS:
+            if (!(value >= 0.0 && value <= 1.0e6) || value != (double)(uint32_t)value) return fail(ctx, PT_ERR_INVALID, "batch ticks must be a count");
+            ctx->batch_ticks = (uint32_t)value;
             return PT_OK;
         case PT_OPT_LIVE_FACTOR:
             if (!(value >= 2.0 && value <= 1.0e6)) return fail(ctx, PT_ERR_INVALID, "live factor must be at least 2");
@@ -958,6 +993,7 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
     }
     for (auto &r : ctx->rolls) free_roll(ctx, r);
     ctx->roll_k = -1;
+    ctx->auto_ticks = 0;
     return PT_OK;
 }
 
@@ -1008,6 +1044,7 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
     ctx->cam = d;
     ctx->have_camera = true;
     ctx->roll_k = -1;
+    ctx->auto_ticks = 0;
     return PT_OK;
 }
 
@@ -1322,6 +1359,8 @@ static int ensure_roll(pt_context *ctx, pt_context::Pipe &pp, pt_context::Roll &
     r.n_live = n_live;
     r.counted = r.tick;
     r.known_rays = 0;
+    r.any_start = false;
+    r.drain_rays.clear();
     return PT_OK;
 }
 
@@ -1354,6 +1393,42 @@ static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
     ctx->profiled_batches++;
 }
 
+// Takes note of the ticks that have finished since the last look (they finish in order).
+static void roll_count_finished(pt_context::Roll &r) {
+    while (r.counted < r.tick && hipEventQuery(r.done[r.counted % pt_context::ROLL_RING]) == hipSuccess) {
+        r.known_rays = r.host_tick_rays[r.counted % pt_context::ROLL_RING];
+        if (r.any_start && r.counted >= r.last_start) {
+            const size_t j = (size_t)(r.counted - r.last_start);
+            if (r.drain_rays.size() <= j) r.drain_rays.resize(j + 1, 0u);
+            r.drain_rays[j] = r.known_rays;
+        }
+        r.counted++;
+    }
+}
+
+// After a drain (every stream idle): from the survivors it counted tick by tick, the number of ticks after which
+// so few paths of a batch are left that finishing them in one go (k_finish) costs less than keeping the batch's
+// slots.  Returns 0 when nothing was learnt.
+static uint32_t roll_learn(pt_context *ctx) {
+    uint32_t best = 0;
+    for (int p = 0; p < ctx->n_roll_pipes; p++) {
+        pt_context::Roll &r = ctx->rolls[p];
+        roll_count_finished(r);
+        if (!r.any_start || r.counted != r.tick || r.cap == 0u || r.drain_rays.empty() || !r.due.empty()) continue;
+        const uint32_t few = std::max<uint32_t>(8u, (uint32_t)((double)r.cap * 3.0e-7));
+        uint32_t ticks = 0;
+        for (size_t j = 0; j < r.drain_rays.size(); j++)
+            if (r.drain_rays[j] <= few) {
+                ticks = (uint32_t)j + 1u;
+                break;
+            }
+        if (ticks == 0u) ticks = r.n_regions < ctx->cam.max_depth ? 2u * r.n_regions : ctx->cam.max_depth;  // more were left than the drain could show
+        ticks = std::max(8u, (ticks + 3u) / 4u * 4u);
+        best = std::max(best, std::min(ticks, ctx->cam.max_depth));
+    }
+    return best;
+}
+
 // One tick of the next pipe in turn.  `nb` (may be null): the batch to start with it; nb->n_slots <= cap.
 // *started (may be null when nb is): whether the batch did start: it does not when its paths and the rays in
 // flight might not fit the pipe's arrays, and the tick then only advances what is under way.
@@ -1368,12 +1443,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
         ctx->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
         return PT_OK;
     };
-    auto count_finished = [&]() {  // ticks finish in order
-        while (r.counted < r.tick && hipEventQuery(r.done[r.counted % pt_context::ROLL_RING]) == hipSuccess) {
-            r.known_rays = r.host_tick_rays[r.counted % pt_context::ROLL_RING];
-            r.counted++;
-        }
-    };
+    auto count_finished = [&]() { roll_count_finished(r); };
     if (r.tick >= (uint64_t)pt_context::ROLL_RING) {  // this tick reuses the ring entry of the tick ROLL_RING before it
         if (int rc = wait_for(r.tick)) return rc;
         harvest_roll(ctx, r, ring);
@@ -1411,7 +1481,10 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
         rp.seed_mixed = nb->seed_mixed;
         rp.stratum_first = nb->stratum_first;
         rp.n_strata = nb->n_strata;
-        r.due.push_back({r.tick + depth - 1u, region, nb->n_strata});
+        r.due.push_back({r.tick + r.n_regions - 1u, region, nb->n_strata});
+        r.last_start = r.tick;
+        r.any_start = true;
+        r.drain_rays.clear();
     }
     r.ring_new[ring] = fp.n_new;
     hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(1), 0, st, ps.regions, region, rp, nb ? 1u : 0u, ps.next_rays);
@@ -1435,7 +1508,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
         // in stratum order over all pipes: ticks go round the pipes, so batches fall due in the order they started
         const pt_context::Due d = r.due.front();
         r.due.pop_front();
-        if (paths_may_outlive_depth(ctx)) launch_finish(ctx, st, ps, common, parity, d.region);
+        if (paths_may_outlive_depth(ctx) || r.n_regions < depth) launch_finish(ctx, st, ps, common, parity, d.region);
         if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_accumulated, 0));
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, common.npix)), dim3(BLOCK), 0, st, ps.contrib + (size_t)d.region * r.cap, ctx->accum, common.npix,
                            d.n_strata);
@@ -1478,9 +1551,9 @@ static uint32_t roll_strata_now(pt_context *ctx) {
     for (int p = 0; p < ctx->n_roll_pipes; p++)
         for (const auto &a : ctx->rolls[p].allocs) have += a.second;  // what is there would be replaced
     const uint64_t budget = have / 2 / (uint64_t)ctx->n_roll_pipes;
-    auto bytes = [&](uint64_t kk) { return roll_bytes(ctx, depth, npix * kk, roll_live(ctx, depth, npix * kk)); };
+    auto bytes = [&](uint64_t kk) { return roll_bytes(ctx, ctx->roll_regions(), npix * kk, roll_live(ctx, depth, npix * kk)); };
     while (k > 1 && bytes(k) > budget) k--;
-    if (bytes(k) > budget || (uint64_t)depth * npix * k > (1ull << 31)) return 0;
+    if (bytes(k) > budget || (uint64_t)ctx->roll_regions() * npix * k > (1ull << 31)) return 0;
     return (uint32_t)k;
 }
 
@@ -1519,11 +1592,12 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         const uint32_t depth = ctx->cam.max_depth, cap_slots = npix * k_tick;
         const uint64_t n_live = roll_live(ctx, depth, cap_slots);
         bool fits = true;
-        for (int p = 0; p < ctx->n_roll_pipes; p++) fits = fits && ctx->rolls[p].n_regions == depth && ctx->rolls[p].cap == cap_slots && ctx->rolls[p].n_live == n_live;
+        const uint32_t regions = ctx->roll_regions();
+        for (int p = 0; p < ctx->n_roll_pipes; p++) fits = fits && ctx->rolls[p].n_regions == regions && ctx->rolls[p].cap == cap_slots && ctx->rolls[p].n_live == n_live;
         if (!fits) {
             sync_pipes(ctx);
             for (int p = 0; p < ctx->n_roll_pipes; p++)
-                if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], depth, cap_slots, n_live))) return rc;
+                if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], regions, cap_slots, n_live))) return rc;
         }
         const uint32_t n_batches = (total + k_tick - 1) / k_tick, per_batch = (total + n_batches - 1) / n_batches;
         for (uint32_t s = stratum_begin; s < stratum_end;) {

@@ -224,3 +224,26 @@ def test_camera_rays_searched_a_wave_at_a_time_give_the_same_bits(name):
     for a, b in zip(got[0], got[1]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.array_equal(got[1][1].view(np.uint32), got[1][2].view(np.uint32))  # both schedules, packets on
+
+
+@pytest.mark.parametrize("make,width", [(scenes.small_mixed, 32), (scenes.cornell, 48), (scenes.extensions_demo, 40)])
+def test_accumulator_identical_however_early_the_last_paths_of_a_batch_are_finished(make, width):
+    # PT_OPT_BATCH_TICKS: 1 = a batch keeps its slots for max_depth launches, n = what is left after n launches is
+    # finished in one go, 0 = learnt from the first drain (so the second half of the render runs with what was learnt)
+    from pathtracer_amd.core import PT_OPT_BATCH_TICKS, PT_OPT_ROLLING
+    src = make(width, 36)
+    ref = None
+    for rolling, ticks in ((0, 1), (1 << 22, 1), (1 << 22, 2), (1 << 22, 3), (1 << 22, 7), (1 << 22, 0), (3 * width * width, 0), (3 * width * width, 2)):
+        r = _renderer(src)
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.set_option(PT_OPT_BATCH_TICKS, ticks)
+        r.render(0, 20, seed=5)
+        r.sync()
+        r.render(20, 29, seed=5)
+        r.render(29, 36, seed=5)
+        acc, n = r.read_accum()
+        assert n == 36
+        if ref is None:
+            ref = acc
+        else:
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"rolling={rolling} ticks={ticks}"
