@@ -167,7 +167,10 @@ enum {
     PT_OPT_MAX_PATHS = 1,               /* upper bound on paths in flight per batch; default 24000000 */
     PT_OPT_PROFILE = 2,                 /* 1: bracket kernels with HIP events, fill *_ms */
     PT_OPT_COUNTERS = 3,                /* 1: count AABB / primitive tests (implies the reference-order traversal) */
-    PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes */
+    PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes;
+                                           2: as 0, and pt_trace_first_hit / _at search for 64 consecutive rays at a time the
+                                           way PT_OPT_PACKET does for camera rays (worlds without an instance buffer), so
+                                           that search can be checked on any rays */
     PT_OPT_PIPES = 5,                   /* streams the batches are spread over; 1..8, default 1 with the rolling schedule
                                            (PT_OPT_ROLLING) and 4 without */
     PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 24 */

@@ -904,6 +904,28 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
         ps.hit2[i] = h.code;
     }
 }
+// The same for 64 consecutive caller-supplied rays per wave, searched together (dev_packet.h): whatever the rays
+// have in common or not, each gets the hit it gets alone.  Worlds without an instance buffer.
+__global__ __launch_bounds__(BLOCK) void k_trace_packet(DevScene sc, PathState ps, uint32_t n) {
+    const uint32_t n_pieces = (n + 63u) / 64u;
+    for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
+        const uint32_t i = piece * 64u + lane_id();
+        const bool active = i < n;
+        float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (active) ro = ps.ray_o[0][i], rd = ps.ray_d[0][i];
+        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w, rd.w);
+        HitState h;
+        h.code = PTD_HIT_MISS;
+        h.u = h.v = 0.0f;
+        h.prim = 0u;
+        const bool plain = sc.boxes_finite != 0u && __ballot(active && !ray_is_plain(r)) == 0ull;
+        packet_hit_world(sc, __ballot(active), plain, r, h);
+        if (active) {
+            ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+            ps.hit2[i] = h.code;
+        }
+    }
+}
 template <bool INSTANCES>
 __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps, uint32_t n, DevStats *stats) {
     LaneStack st;

@@ -45,6 +45,7 @@ struct pt_context {
     uint64_t max_paths = 24000000;
     bool profile = false, counters = false;
     bool force_ref_order = false;  // PT_OPT_TRAVERSAL = 1
+    bool trace_packet = false;     // PT_OPT_TRAVERSAL = 2: first-hit queries a wave at a time where the scene allows it
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
@@ -477,7 +478,11 @@ int pt_set_option(pt_context *ctx, int key, double value) {
             return PT_OK;
         }
         case PT_OPT_COUNTERS: ctx->counters = value != 0.0; return PT_OK;
-        case PT_OPT_TRAVERSAL: ctx->force_ref_order = value != 0.0; return PT_OK;
+        case PT_OPT_TRAVERSAL:
+            if (value != 0.0 && value != 1.0 && value != 2.0) return fail(ctx, PT_ERR_INVALID, "traversal must be 0, 1 or 2");
+            ctx->force_ref_order = value == 1.0;
+            ctx->trace_packet = value == 2.0;
+            return PT_OK;
         case PT_OPT_PIPES:
             if (!(value >= 1.0 && value <= (double)pt_context::MAX_PIPES)) return fail(ctx, PT_ERR_INVALID, "pipes must be in [1,%d]", pt_context::MAX_PIPES);
             sync_pipes(ctx);
@@ -1750,7 +1755,9 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
         hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, pp.ps, (uint32_t)n);
         const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
         const bool insts = ctx->scene.world.insts.prim_count != 0;
-        if (ctx->use_wide()) {
+        if (ctx->trace_packet && ctx->packet_ok) {
+            hipLaunchKernelGGL(k_trace_packet, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+        } else if (ctx->use_wide()) {
             if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
             else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
         } else {

@@ -24,7 +24,7 @@ def test_raygen_bit_exact(name):
         assert bits_equal(ro, rd)
 
 
-@pytest.mark.parametrize("traversal", [0, 1], ids=["wide", "reference_order"])
+@pytest.mark.parametrize("traversal", [0, 1, 2], ids=["wide", "reference_order", "wave_at_a_time"])
 @pytest.mark.parametrize("name", ["cornell", "small_mixed", "knob"])
 def test_first_hit_ids_exact(name, traversal):
     from pathtracer_amd.core import PT_OPT_TRAVERSAL
