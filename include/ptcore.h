@@ -169,7 +169,7 @@ enum {
     PT_OPT_COUNTERS = 3,                /* 1: count AABB / primitive tests (implies the reference-order traversal) */
     PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes;
                                            2: as 0, and pt_trace_first_hit / _at search for 64 consecutive rays at a time the
-                                           way PT_OPT_PACKET does for camera rays (worlds without an instance buffer), so
+                                           way PT_OPT_PACKET does for camera rays (scenes without device-built BVHs), so
                                            that search can be checked on any rays */
     PT_OPT_PIPES = 5,                   /* streams the batches are spread over; 1..8, default 1 with the rolling schedule
                                            (PT_OPT_ROLLING) and 4 without */
@@ -193,7 +193,7 @@ enum {
     PT_OPT_PACKET = 14,                 /* 1 (default): the paths that start with a launch (camera rays: 64 consecutive ones are
                                            a few neighbouring pixels with all their strata) are searched a wave at a time,
                                            the wave walking the reference's loop once with a lane mask, nodes and triangles
-                                           read once per wave; worlds without an instance buffer only.  0: every ray on
+                                           read once per wave (scenes without device-built BVHs).  0: every ray on
                                            its own, as the rays of later bounces always are.  Same results either way */
     PT_OPT_BATCH_TICKS = 15,            /* rolling schedule: launches a batch takes part in before the few paths it still has are
                                            finished in one go; its per-path sums are held that long, so this sets the

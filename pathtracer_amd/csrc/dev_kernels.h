@@ -347,9 +347,9 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
 
 // PrimitiveBuffer::hit for the paths that start with this step, 64 consecutive slots per wave: a few neighbouring
 // pixels with all the strata of the batch, rays that differ by a fraction of a pixel.  The wave searches for
-// all of them at once (dev_packet.h); each lane's own sequence of tests is the reference's.  For worlds without
-// an instance buffer whose BVHs have reference-order nodes; the rays queued by earlier steps go through
-// k_extend_walk, launched beside this kernel with no fresh paths of its own.
+// all of them at once (dev_packet.h); each lane's own sequence of tests is the reference's.  For scenes whose
+// BVHs all have reference-order nodes; the rays queued by earlier steps go through k_extend_walk, launched
+// beside this kernel with no fresh paths of its own.
 template <bool MOVING>
 __global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
     const WorkList wl = work_list(ps, bounce, fp);
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
     }
 }
 // The same for 64 consecutive caller-supplied rays per wave, searched together (dev_packet.h): whatever the rays
-// have in common or not, each gets the hit it gets alone.  Worlds without an instance buffer.
+// have in common or not, each gets the hit it gets alone.
 __global__ __launch_bounds__(BLOCK) void k_trace_packet(DevScene sc, PathState ps, uint32_t n) {
     const uint32_t n_pieces = (n + 63u) / 64u;
     for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {

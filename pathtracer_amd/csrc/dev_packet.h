@@ -19,9 +19,10 @@
 
 namespace ptd {
 
-// stack entries per wave: two per level in the worst case (lanes that disagree about the near child),
-// trees are at most 64 levels deep (checked at upload)
-constexpr int PACKET_LEVELS = 2 * 64 + 8;
+// stack entries per wave: two per level in the worst case (lanes that disagree about the near child), trees
+// are at most 64 levels deep (checked at upload), and the tree of an instanced set is searched with the
+// entries of the world's instance tree still in place below it
+constexpr int PACKET_LEVELS = 2 * (2 * 64 + 4);
 __shared__ uint32_t g_packet_stack[BLOCK / 64][PACKET_LEVELS][3];
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -40,21 +41,23 @@ struct ScalarF4 {
 };
 __device__ __forceinline__ ScalarF4 scalar_f4(const float4 *q) { return ScalarF4{(const __attribute__((address_space(4))) v4f *)q}; }
 
-// leaf(g, on): primitive g (the same in every lane) for the lanes with on == true.
+// leaf(g, on, sp): primitive g (the same in every lane) for the lanes with on == true; sp = the wave's stack
+// entries in use at that moment (a leaf that searches another tree starts its own above them).
 // `plain`: no lane of the wave can produce a NaN in the box test (ray_is_plain), finite boxes.
+// `floor`: stack entries below it belong to an enclosing search.
 template <class LeafFn>
-__device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuffer &buf, unsigned long long active, bool plain, TravRay &r,
+__device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuffer &buf, unsigned long long active, bool plain, TravRay &r, int floor,
                                                 LeafFn &&leaf) {
     if (buf.prim_count == 0u || active == 0ull) return;
     const unsigned long long lane_bit = 1ull << lane_id();
     if (buf.node_count == 0u) {  // no BVH: src/bvh.rs:726-737
 #pragma unroll 1
-        for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i, (active & lane_bit) != 0ull);
+        for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i, (active & lane_bit) != 0ull, floor);
         return;
     }
     const ScalarF4 nodes = scalar_f4(sc.nodes + 2 * (size_t)buf.node_first);
     uint32_t(*stack)[3] = g_packet_stack[threadIdx.x / 64u];
-    int sp = 0;
+    int sp = floor;
     uint32_t cur = 0u;
     unsigned long long mask = active;
     for (;;) {
@@ -97,11 +100,11 @@ __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuf
             } else {
                 const uint32_t cnt = b & 0xFFFFu;
 #pragma unroll 1
-                for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i, hit);
+                for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i, hit, sp);
             }
         }
         if (!descend) {
-            if (sp == 0) break;
+            if (sp == floor) break;
             sp--;
             cur = uniform(stack[sp][0]);
             mask = (unsigned long long)uniform(stack[sp][1]) | ((unsigned long long)uniform(stack[sp][2]) << 32);
@@ -109,21 +112,52 @@ __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuf
     }
 }
 
-// The triangle, sphere and quad buffers of the world, in that order (PrimitiveBuffer::hit, src/objects.rs:192-194),
-// for a wave of rays; lanes outside `active` have no ray.
-__device__ __forceinline__ void packet_hit_world(const DevScene &sc, unsigned long long active, bool plain, TravRay &r, HitState &h) {
+// The triangle, sphere and quad buffers of one PrimitiveBuffer, in that order (src/objects.rs:192-194), for a
+// wave of rays; lanes outside `active` have no ray.
+__device__ __forceinline__ void packet_hit_set(const DevScene &sc, const DevSet &set, unsigned long long active, bool plain, TravRay &r, HitState &h,
+                                               uint32_t inst_code, int floor) {
     const ScalarF4 tri_hot = scalar_f4(sc.tri_hot), spheres = scalar_f4(sc.spheres), quads = scalar_f4(sc.quads);
-    packet_traverse(sc, sc.world.tris, active, plain, r, [&](uint32_t g, bool on) {
+    packet_traverse(sc, set.tris, active, plain, r, floor, [&](uint32_t g, bool on, int) {
         const float4 a = tri_hot[3u * g], b = tri_hot[3u * g + 1u], c = tri_hot[3u * g + 2u];
-        if (on) hit_tri(a, b, c, g, r, h, 0u);
+        if (on) hit_tri(a, b, c, g, r, h, inst_code);
     });
-    packet_traverse(sc, sc.world.spheres, active, plain, r, [&](uint32_t g, bool on) {
+    packet_traverse(sc, set.spheres, active, plain, r, floor, [&](uint32_t g, bool on, int) {
         const float4 s = spheres[g];
-        if (on) hit_sphere(s, g, r, h, 0u);
+        if (on) hit_sphere(s, g, r, h, inst_code);
     });
-    packet_traverse(sc, sc.world.quads, active, plain, r, [&](uint32_t g, bool on) {
+    packet_traverse(sc, set.quads, active, plain, r, floor, [&](uint32_t g, bool on, int) {
         const float4 q0 = quads[4u * g], q1 = quads[4u * g + 1u], q2 = quads[4u * g + 2u], q3 = quads[4u * g + 3u];
-        if (on) hit_quad(q0, q1, q2, q3, g, r, h, 0u);
+        if (on) hit_quad(q0, q1, q2, q3, g, r, h, inst_code);
+    });
+}
+
+// PrimitiveBuffer::hit on the world (src/objects.rs:191-197): its own three buffers, then its instance buffer, where
+// a "primitive" is an instance: the lanes that reach it take their rays into its frame (Instance::hit,
+// src/objects.rs:384-401: direction not renormalised, so t is shared between the frames), the wave searches the
+// instanced set's buffers for them above the stack entries of the instance tree, and a hit in there replaces
+// the lane's hit and shortens its ray as the reference's local HitRecord does when it is copied out.
+__device__ __forceinline__ void packet_hit_world(const DevScene &sc, unsigned long long active, bool plain, TravRay &r, HitState &h) {
+    packet_hit_set(sc, sc.world, active, plain, r, h, 0u, 0);
+    const ScalarF4 insts = scalar_f4(sc.insts);
+    packet_traverse(sc, sc.world.insts, active, plain, r, 0, [&](uint32_t gi, bool on, int sp) {
+        Affine inv;
+        const float4 r0 = insts[7u * gi], r1 = insts[7u * gi + 1u], r2 = insts[7u * gi + 2u], last = insts[7u * gi + 6u];
+        inv.m[0] = r0.x, inv.m[1] = r0.y, inv.m[2] = r0.z, inv.m[3] = r0.w;
+        inv.m[4] = r1.x, inv.m[5] = r1.y, inv.m[6] = r1.z, inv.m[7] = r1.w;
+        inv.m[8] = r2.x, inv.m[9] = r2.y, inv.m[10] = r2.z, inv.m[11] = r2.w;
+        const uint32_t child = uniform(__float_as_uint(last.x));
+        TravRay local = make_trav_ray(xf_point(inv, r.o), xf_vector(inv, r.d), r.t_min, r.t_max);
+        HitState hl;
+        hl.code = PTD_HIT_MISS;
+        hl.u = hl.v = 0.0f;
+        hl.prim = 0u;
+        const unsigned long long in = __ballot(on);
+        const bool plain_local = sc.boxes_finite != 0u && __ballot(on && !ray_is_plain(local)) == 0ull;
+        packet_hit_set(sc, sc.sets[child], in, plain_local, local, hl, (gi - sc.world.insts.prim_first + 1u) << 2, sp);
+        if (on && hl.code != PTD_HIT_MISS) {
+            h = hl;
+            r.t_max = local.t_max;
+        }
     });
 }
 

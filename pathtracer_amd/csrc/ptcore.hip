@@ -49,8 +49,8 @@ struct pt_context {
     bool wide_ok = false;          // every leaf fits the packed wide-node reference
     uint32_t stack_need = 0;       // bound on traversal stack entries for this scene
     bool use_wide() const { return wide_ok && !force_ref_order; }
-    // The paths that start with a step are searched a wave at a time (k_extend_packet): worlds without an instance
-    // buffer whose BVHs come with reference-order nodes (packet_ok, decided at upload).
+    // The paths that start with a step are searched a wave at a time (k_extend_packet): scenes whose BVHs all come
+    // with reference-order nodes (packet_ok, decided at upload).
     bool packet_ok = false, packet = true;  // PT_OPT_PACKET
     bool use_packet() const { return packet && packet_ok && use_wide() && !counters; }
 #ifdef PT_WALK_WAVES
@@ -863,7 +863,9 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         ctx->stack_need = std::max(set_depth(0), depth_of[0][3] + child_depth) + 4u;
         ctx->wide_ok = wide_ok;
         const DevSet &w = sets[0];
-        ctx->packet_ok = w.insts.prim_count == 0u && w.tris.tree != 2u && w.spheres.tree != 2u && w.quads.tree != 2u;
+        ctx->packet_ok = true;  // every set a ray can get into has reference-order nodes (or no tree at all)
+        for (const DevSet &ds : sets) ctx->packet_ok = ctx->packet_ok && ds.tris.tree != 2u && ds.spheres.tree != 2u && ds.quads.tree != 2u && ds.insts.tree != 2u;
+        (void)w;
     }
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->quad_mat, s->n_quads))) return rc;
     d.quad_mat = pi;

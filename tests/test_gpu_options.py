@@ -201,9 +201,12 @@ def _packet_scenes():
     yield "lucy", scenes.lucy(width=72, spp=36, max_depth=8, detail=0.1)
     yield "moving", moving((-2.0, 0.0, 0.0), (2.0, 0.5, 0.0), width=40, spp=36, depth=6, extras=True)
     yield "one_row", scenes.knob(width=7, spp=36, max_depth=5, detail=0.1)
+    yield "cornell", scenes.cornell(56, 36)  # two instances
+    yield "next_week", scenes.next_week_like(48, 36, max_depth=12, extensions=True)  # 401 instances, media, a moving sphere
+    yield "small_mixed", scenes.small_mixed(40, 36)
 
 
-@pytest.mark.parametrize("name", ["knob", "interior", "lucy", "moving", "one_row"])
+@pytest.mark.parametrize("name", ["knob", "interior", "lucy", "moving", "one_row", "cornell", "next_week", "small_mixed"])
 def test_camera_rays_searched_a_wave_at_a_time_give_the_same_bits(name):
     # PT_OPT_PACKET: per-sample radiance (one batch at a time) and the accumulator (rolling schedule) with and without
     from pathtracer_amd.core import PT_OPT_PACKET, PT_OPT_ROLLING

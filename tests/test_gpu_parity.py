@@ -51,7 +51,7 @@ def test_random_and_degenerate_rays_both_traversals(name):
     onsurf[:, 7] = np.inf
     rays = np.concatenate([rays, onsurf])
     ids, tuv = o.trace(rays)
-    for mode in (0, 1, 2):  # 2: 64 consecutive rays searched together (no effect on worlds with instances)
+    for mode in (0, 1, 2):  # 2: 64 consecutive rays searched together
         r.set_option(PT_OPT_TRAVERSAL, mode)
         h = r.trace(rays)
         assert np.array_equal(h["prim_type"], ids[:, 0]), mode
