@@ -350,7 +350,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
 // all of them at once (dev_packet.h); each lane's own sequence of tests is the reference's.  For scenes whose
 // BVHs all have reference-order nodes; the rays queued by earlier steps go through k_extend_walk, launched
 // beside this kernel with no fresh paths of its own.
-template <bool MOVING>
+template <bool INSTANCES, bool MOVING>
 __global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp, DevStats *stats) {
     const WorkList wl = work_list(ps, bounce, fp);
     if (blockIdx.x == 0 && threadIdx.x == 0 && fp.n_new) {
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera 
         }
         TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
         const bool plain = sc.boxes_finite != 0u && __ballot(active && !ray_is_plain(r)) == 0ull;
-        packet_hit_world(sc, __ballot(active), plain, r, h);
+        packet_hit_world<INSTANCES>(sc, __ballot(active), plain, r, h);
         if (active) {
             if constexpr (MOVING) {
                 TravCounters tc{0, 0, 0, 0};
@@ -906,6 +906,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace(DevScene sc, PathState ps, uint
 }
 // The same for 64 consecutive caller-supplied rays per wave, searched together (dev_packet.h): whatever the rays
 // have in common or not, each gets the hit it gets alone.
+template <bool INSTANCES>
 __global__ __launch_bounds__(BLOCK) void k_trace_packet(DevScene sc, PathState ps, uint32_t n) {
     const uint32_t n_pieces = (n + 63u) / 64u;
     for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
@@ -919,7 +920,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_packet(DevScene sc, PathState p
         h.u = h.v = 0.0f;
         h.prim = 0u;
         const bool plain = sc.boxes_finite != 0u && __ballot(active && !ray_is_plain(r)) == 0ull;
-        packet_hit_world(sc, __ballot(active), plain, r, h);
+        packet_hit_world<INSTANCES>(sc, __ballot(active), plain, r, h);
         if (active) {
             ps.hit[i] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
             ps.hit2[i] = h.code;

@@ -136,8 +136,11 @@ __device__ __forceinline__ void packet_hit_set(const DevScene &sc, const DevSet 
 // src/objects.rs:384-401: direction not renormalised, so t is shared between the frames), the wave searches the
 // instanced set's buffers for them above the stack entries of the instance tree, and a hit in there replaces
 // the lane's hit and shortens its ray as the reference's local HitRecord does when it is copied out.
+// INSTANCES: the world has an instance buffer (the code for it costs a third of the registers).
+template <bool INSTANCES>
 __device__ __forceinline__ void packet_hit_world(const DevScene &sc, unsigned long long active, bool plain, TravRay &r, HitState &h) {
     packet_hit_set(sc, sc.world, active, plain, r, h, 0u, 0);
+    if constexpr (!INSTANCES) return;
     const ScalarF4 insts = scalar_f4(sc.insts);
     packet_traverse(sc, sc.world.insts, active, plain, r, 0, [&](uint32_t gi, bool on, int sp) {
         Affine inv;

@@ -1161,8 +1161,13 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
             (void)hipEventRecord(fork, st);
             (void)hipStreamWaitEvent(side, fork, 0);
             const dim3 gp((unsigned)std::min<uint64_t>(((uint64_t)fp.n_new + BLOCK - 1) / BLOCK, (uint64_t)ctx->n_cu * 8u));
-            if (ctx->scene.n_moving != 0) hipLaunchKernelGGL((k_extend_packet<true>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats);
-            else hipLaunchKernelGGL((k_extend_packet<false>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats);
+#define EXP(I, M) hipLaunchKernelGGL((k_extend_packet<I, M>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
+            if (ctx->scene.n_moving != 0) {
+                if (insts) EXP(true, true); else EXP(false, true);
+            } else {
+                if (insts) EXP(true, false); else EXP(false, false);
+            }
+#undef EXP
             (void)hipEventRecord(join, side);
             walk_fp.n_new = 0u;
         }
@@ -1758,7 +1763,8 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
         const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
         const bool insts = ctx->scene.world.insts.prim_count != 0;
         if (ctx->trace_packet && ctx->packet_ok) {
-            hipLaunchKernelGGL(k_trace_packet, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            if (insts) hipLaunchKernelGGL((k_trace_packet<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
+            else hipLaunchKernelGGL((k_trace_packet<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         } else if (ctx->use_wide()) {
             if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
             else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
