@@ -122,7 +122,7 @@ def main():
     if args.tail_below >= 0:
         r.set_option(PT_OPT_TAIL_BELOW, args.tail_below)
     if args.rolling >= 0:
-        if args.rolling > 24_000_000:  # beyond the library's default cap on paths per batch
+        if args.rolling > 32_000_000:  # beyond the library's default cap on paths per batch
             r.set_option(PT_OPT_MAX_PATHS, args.rolling)
         r.set_option(PT_OPT_ROLLING, args.rolling)
     if args.live_factor:
@@ -239,7 +239,7 @@ def main():
                        "strata_per_step": S, "parallelism": f"spp-sharded x{world}, one reduce",
                        "integrator": args.integrator, "bsdf_sample_probability": args.bsdf_probability,
                        "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
-                                    "library default (rolling, one pipe, up to 24 M paths started per launch)" if args.rolling < 0 else "one batch at a time per pipe")},
+                                    "library default (rolling, one pipe, up to 32 M paths started per launch)" if args.rolling < 0 else "one batch at a time per pipe")},
             "roofline": {"bound": "hbm", "kernel": "k_extend_walk + k_extend_packet (one step's closest-hit search: queued rays and new paths, side by side)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "hbm_counter_frac": hbm_counter_frac, "valu_issue_frac": valu_issue_frac, "lane_util": lane_util,

@@ -164,7 +164,7 @@ typedef struct pt_stats {
 
 enum {
     PT_OPT_BSDF_SAMPLE_PROBABILITY = 0, /* BSDF_SAMPLE_PROBABILITY of src/camera.rs:317; default 1.0 */
-    PT_OPT_MAX_PATHS = 1,               /* upper bound on paths in flight per batch; default 24000000 */
+    PT_OPT_MAX_PATHS = 1,               /* upper bound on paths in flight per batch; default 32000000 */
     PT_OPT_PROFILE = 2,                 /* 1: bracket kernels with HIP events, fill *_ms */
     PT_OPT_COUNTERS = 3,                /* 1: count AABB / primitive tests (implies the reference-order traversal) */
     PT_OPT_TRAVERSAL = 4,               /* 0 (default): 64-byte two-box nodes; 1: the reference's loop over 32-byte nodes;
@@ -178,7 +178,7 @@ enum {
     PT_OPT_BLOCKS_PER_CU = 8,           /* resident workgroups per CU of the traversal kernels; 1..5, default 5 */
     PT_OPT_ROLLING = 10,                /* paths started per launch of the rolling schedule, in which every launch carries
                                            bounce 0 of a new batch together with the later bounces of the batches before it;
-                                           0 = one batch at a time per pipe; default 24000000 */
+                                           0 = one batch at a time per pipe; default 32000000 */
     PT_OPT_DEVICE_BVH = 11,             /* a triangle buffer that is uploaded without nodes and has at least this many
                                            triangles gets its BVH built on the device during pt_upload_scene (a different
                                            tree from the host builder's: same closest distances, the winner among exact

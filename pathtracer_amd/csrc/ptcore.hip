@@ -42,7 +42,7 @@ struct pt_context {
 
     // options
     float bsdf_prob = 1.0f;
-    uint64_t max_paths = 24000000;
+    uint64_t max_paths = 32000000;
     bool profile = false, counters = false;
     bool force_ref_order = false;  // PT_OPT_TRAVERSAL = 1
     bool trace_packet = false;     // PT_OPT_TRAVERSAL = 2: first-hit queries a wave at a time where the scene allows it
@@ -152,7 +152,7 @@ struct pt_context {
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
     int64_t roll_k = -1;             // strata per tick decided for the current scene, camera and options (-1: not yet)
     uint64_t untraced_paths = 0;  // camera paths of renders with max_depth 0, which start and end on the host
-    uint64_t roll_paths = 24000000;  // paths started per tick; 0 = one batch at a time per pipe
+    uint64_t roll_paths = 32000000;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;       // batch-at-a-time schedule
     int n_roll_pipes = 1;  // rolling schedule: its launches are all large; a second pipe gains 0-3 % and doubles the path state
     uint64_t batch_seq = 0;                 // batches enqueued so far (picks the pipe)
@@ -1145,9 +1145,11 @@ static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
 // One closest-hit step.  Counting AABB / primitive tests implies the reference-order loop.
 // fp: the paths that start with this step (on their camera rays; nothing is stored for them).
 // side, fork, join: a second stream of the pipe with two events (or null): where k_extend_packet runs.
+// queued: about how many rays the ray queue holds (the last count the host has seen).
 static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, FreshPaths fp, hipStream_t side = nullptr,
-                          hipEvent_t fork = nullptr, hipEvent_t join = nullptr) {
-    const dim3 g(grid), b(BLOCK);
+                          hipEvent_t fork = nullptr, hipEvent_t join = nullptr, uint64_t queued = 0) {
+    dim3 g(grid);
+    const dim3 b(BLOCK);
     const f3 bg = ctx->cam.background;
     const bool insts = ctx->scene.world.insts.prim_count != 0;
 #define EXT(C, K) hipLaunchKernelGGL((k_extend<C, K>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
@@ -1160,7 +1162,13 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
             // the new paths a wave at a time, beside the rays queued by earlier steps
             (void)hipEventRecord(fork, st);
             (void)hipStreamWaitEvent(side, fork, 0);
-            const dim3 gp((unsigned)std::min<uint64_t>(((uint64_t)fp.n_new + BLOCK - 1) / BLOCK, (uint64_t)ctx->n_cu * 8u));
+            // The two kernels share a CU only if the walking one leaves registers free: five of its waves per SIMD
+            // take 480 of the 512 VGPRs, and a wave of this one needs 64.  Where most of the step's rays are new
+            // paths the walking kernel runs with four; where the queued rays are the larger part it keeps five
+            // (1 M-triangle box, interior: 0 to -3 % with four, knob: +9 %).
+            const bool mostly_new = (uint64_t)fp.n_new >= queued;
+            const unsigned per_cu = mostly_new ? 16u : 8u;
+            const dim3 gp((unsigned)std::min<uint64_t>(((uint64_t)fp.n_new + BLOCK - 1) / BLOCK, (uint64_t)ctx->n_cu * per_cu));
 #define EXP(I, M) hipLaunchKernelGGL((k_extend_packet<I, M>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
             if (ctx->scene.n_moving != 0) {
                 if (insts) EXP(true, true); else EXP(false, true);
@@ -1170,6 +1178,8 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
 #undef EXP
             (void)hipEventRecord(join, side);
             walk_fp.n_new = 0u;
+            const int beside = mostly_new ? 4 : 5;
+            if (beside < ctx->blocks_per_cu) g = dim3(std::min<unsigned>(g.x, (unsigned)grid_fixed(ctx, ~0ull >> 1, beside)));
         }
 #define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, walk_fp, ctx->stats)
         if (ctx->scene.n_moving != 0) {
@@ -1502,7 +1512,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
     hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(1), 0, st, ps.regions, region, rp, nb ? 1u : 0u, ps.next_rays);
     if (prof) (void)hipEventRecord(r.prof[ring][1], st);
     const uint64_t bound = r.n_live + r.cap;
-    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp, pp.side[0], pp.fork, pp.join[0]);
+    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp, pp.side[0], pp.fork, pp.join[0], r.known_rays);
     if (prof) (void)hipEventRecord(r.prof[ring][2], st);
     BatchParams common{};
     common.npix = ctx->cam.width * ctx->cam.height;
