@@ -1574,8 +1574,10 @@ static uint32_t roll_strata_now(pt_context *ctx) {
         for (const auto &a : ctx->rolls[p].allocs) have += a.second;  // what is there would be replaced
     const uint64_t budget = have / 2 / (uint64_t)ctx->n_roll_pipes;
     auto bytes = [&](uint64_t kk) { return roll_bytes(ctx, ctx->roll_regions(), npix * kk, roll_live(ctx, depth, npix * kk)); };
-    while (k > 1 && bytes(k) > budget) k--;
-    if (bytes(k) > budget || (uint64_t)ctx->roll_regions() * npix * k > (1ull << 31)) return 0;
+    // slots are 32-bit numbers, and every region of a pipe has them
+    auto too_big = [&](uint64_t kk) { return bytes(kk) > budget || (uint64_t)ctx->roll_regions() * npix * kk > (1ull << 31); };
+    while (k > 1 && too_big(k)) k--;
+    if (too_big(k)) return 0;
     return (uint32_t)k;
 }
 
