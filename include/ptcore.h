@@ -173,8 +173,8 @@ enum {
                                            that search can be checked on any rays */
     PT_OPT_PIPES = 5,                   /* streams the batches are spread over; 1..8, default 1 with the rolling schedule
                                            (PT_OPT_ROLLING) and 4 without */
-    PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 24 */
-    PT_OPT_LEAF_BATCH = 7,              /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 8 */
+    PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 32 */
+    PT_OPT_LEAF_BATCH = 7,              /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 16 */
     PT_OPT_BLOCKS_PER_CU = 8,           /* resident workgroups per CU of the traversal kernels; 1..5, default 5 */
     PT_OPT_ROLLING = 10,                /* paths started per launch of the rolling schedule, in which every launch carries
                                            bounce 0 of a new batch together with the later bounces of the batches before it;

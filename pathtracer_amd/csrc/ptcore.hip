@@ -58,7 +58,7 @@ struct pt_context {
 #else
     int blocks_per_cu = 5;  // as many as the LDS stacks allow: measured 0.4 - 4 % faster than 4 on every scene
 #endif
-    int refill_below = 24, leaf_batch = 8, shade_blocks_per_cu = 8;
+    int refill_below = 32, leaf_batch = 16, shade_blocks_per_cu = 8;
     bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
     uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
     double live_factor = 4.0;  // PT_OPT_LIVE_FACTOR
