@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dev_packet.h"
 #include "dev_shade.h"
 #include "dev_walk.h"
@@ -115,6 +117,12 @@ struct WorkList {
         return pos - queued < fp.n_new ? fp.new_base + (pos - queued) : QUEUE_EMPTY;
     }
 };
+// The work list of a launch that carries no fresh paths (they have a kernel of their own beside it): the same, with
+// "no position is fresh" known at compile time, so that the code for camera rays is not part of that launch.
+struct QueuedOnly : WorkList {
+    __device__ __forceinline__ bool fresh(uint32_t) const { return false; }
+    __device__ __forceinline__ uint32_t slot(const PathState &ps, uint32_t pos) const { return pos < queued ? ps.ray_queue[parity][pos] : QUEUE_EMPTY; }
+};
 __device__ __forceinline__ WorkList work_list(const PathState &ps, uint32_t bounce, FreshPaths fp) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
@@ -131,7 +139,8 @@ __device__ __forceinline__ void fresh_path(const DevCamera &cam, const PathState
     time = ps.moving ? path_time(rng.key) : 0.0f;
 }
 // Origin and direction of the ray at a position of the work list (which holds a path: not padding).
-__device__ __forceinline__ void path_ray(const DevCamera &cam, const PathState &ps, const WorkList &wl, uint32_t pos, f3 &o, f3 &d) {
+template <class WL>
+__device__ __forceinline__ void path_ray(const DevCamera &cam, const PathState &ps, const WL &wl, uint32_t pos, f3 &o, f3 &d) {
     if (wl.fresh(pos)) {
         uint32_t draws;
         float time;
@@ -170,7 +179,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // material finish here (src/camera.rs:371, :277-283); the others are appended (by their position in the work
 // list) to the queue of their material type.  Every lane of the wave must call this (inactive lanes with
 // active == false), after shade_push_init() and before shade_push_close().
-__device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, const WorkList &wl, f3 background, bool active, uint32_t pos, uint32_t code,
+template <class WL>
+__device__ __forceinline__ void classify(const DevScene &sc, const PathState &ps, const WL &wl, f3 background, bool active, uint32_t pos, uint32_t code,
                                          uint32_t prim) {
     uint32_t qslot = 0xFFu;
     if (active) {
@@ -243,7 +253,8 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 // three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
 // A scene with moving spheres (pts_moving_sphere) tests them last, where they are at the path's time.
-__device__ __forceinline__ float path_time_at(const DevCamera &cam, const PathState &ps, const WorkList &wl, uint32_t pos) {
+template <class WL>
+__device__ __forceinline__ float path_time_at(const DevCamera &cam, const PathState &ps, const WL &wl, uint32_t pos) {
     if (!wl.fresh(pos)) return ps.beta[wl.parity][pos].w;
     f3 o, d;
     uint32_t draws;
@@ -301,10 +312,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, DevCamera cam, Pa
 #define WALK_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_WALK_WAVES, PT_WALK_WAVES)))
 // MOVING: the scene has moving spheres (pts_moving_sphere): a finished ray is tested against them, where
 // they are at its path's time, before it is classified.
-template <bool INSTANCES, bool MOVING>
+// FRESH: the launch may carry paths that start with it (false: they are in k_extend_packet's hands, fp.n_new is 0).
+template <bool INSTANCES, bool MOVING, bool FRESH>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp,
                                                                       DevStats *stats) {
-    const WorkList wl = work_list(ps, bounce, fp);
+    const WorkList full = work_list(ps, bounce, fp);
+    typedef typename std::conditional<FRESH, WorkList, QueuedOnly>::type List;
+    const List wl{full};
     extend_prologue(ps, bounce, wl.queued, fp.n_new, stats);
     const uint32_t n_pieces = wl.n_pieces();
     if (n_pieces == 0u) return;

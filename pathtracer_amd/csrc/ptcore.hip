@@ -1181,12 +1181,14 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
             const int beside = mostly_new ? 4 : 5;
             if (beside < ctx->blocks_per_cu) g = dim3(std::min<unsigned>(g.x, (unsigned)grid_fixed(ctx, ~0ull >> 1, beside)));
         }
-#define EXW(I, M) hipLaunchKernelGGL((k_extend_walk<I, M>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, walk_fp, ctx->stats)
+#define EXW(I, M, F) hipLaunchKernelGGL((k_extend_walk<I, M, F>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, walk_fp, ctx->stats)
+#define EXWF(I, M) do { if (walk_fp.n_new != 0u) EXW(I, M, true); else EXW(I, M, false); } while (0)
         if (ctx->scene.n_moving != 0) {
-            if (insts) EXW(true, true); else EXW(false, true);
+            if (insts) EXWF(true, true); else EXWF(false, true);
         } else {
-            if (insts) EXW(true, false); else EXW(false, false);
+            if (insts) EXWF(true, false); else EXWF(false, false);
         }
+#undef EXWF
 #undef EXW
         if (walk_fp.n_new != fp.n_new) (void)hipStreamWaitEvent(st, join, 0);
     } else {
