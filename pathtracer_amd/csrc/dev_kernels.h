@@ -75,17 +75,26 @@ __device__ __forceinline__ void shade_push_close(const PathState &ps) {
 }
 
 // Camera::get_ray (src/camera.rs:238-260) for one (pixel, stratum).
-__device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint32_t pixel, uint32_t stratum, f3 &o, f3 &d) {
+// `known` (0: unknown): the number of draws this ray is known to consume.  The generator is counter-based, so the
+// draws that made the ray (the accepted point of the disk, then the two of the square) can be taken directly
+// instead of repeating the rejection loop that led to them.
+__device__ __forceinline__ void camera_ray(const DevCamera &cam, Rng &rng, uint32_t pixel, uint32_t stratum, f3 &o, f3 &d, uint32_t known = 0u) {
     const float u = (float)(pixel % cam.width), v = (float)(pixel / cam.width);
     const float s_u = (float)(stratum / cam.sqrt_spp), s_v = (float)(stratum % cam.sqrt_spp);
     float disk_u, disk_v;
-    for (;;) {  // DiskSampler::unit(), src/types/sampler.rs:49-58: drawn even when there is no lens
-        float x = rng.range(-1.0f, 1.0f);
-        float y = rng.range(-1.0f, 1.0f);
-        if (x * x + y * y < 1.0f) {
-            disk_u = x;
-            disk_v = y;
-            break;
+    if (known >= 4u) {
+        rng.counter += known - 4u;
+        disk_u = rng.range(-1.0f, 1.0f);
+        disk_v = rng.range(-1.0f, 1.0f);
+    } else {
+        for (;;) {  // DiskSampler::unit(), src/types/sampler.rs:49-58: drawn even when there is no lens
+            float x = rng.range(-1.0f, 1.0f);
+            float y = rng.range(-1.0f, 1.0f);
+            if (x * x + y * y < 1.0f) {
+                disk_u = x;
+                disk_v = y;
+                break;
+            }
         }
     }
     f3 ray_center = cam.center;
@@ -128,13 +137,14 @@ __device__ __forceinline__ WorkList work_list(const PathState &ps, uint32_t boun
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     return WorkList{parity, n_chunks * QUEUE_CHUNK, fp};
 }
-__device__ __forceinline__ void fresh_path(const DevCamera &cam, const PathState &ps, uint32_t slot, f3 &o, f3 &d, uint32_t &draws, float &time) {
+__device__ __forceinline__ void fresh_path(const DevCamera &cam, const PathState &ps, uint32_t slot, f3 &o, f3 &d, uint32_t &draws, float &time,
+                                           uint32_t known = 0u) {
     uint64_t seed_mixed;
     uint32_t pixel, stratum;
     path_sample(ps, slot, seed_mixed, pixel, stratum);
     Rng rng;
     rng.init(seed_mixed, pixel, stratum, 0u);
-    camera_ray(cam, rng, pixel, stratum, o, d);
+    camera_ray(cam, rng, pixel, stratum, o, d, known);
     draws = rng.counter;
     time = ps.moving ? path_time(rng.key) : 0.0f;
 }
@@ -145,6 +155,7 @@ __device__ __forceinline__ void path_ray(const DevCamera &cam, const PathState &
         uint32_t draws;
         float time;
         fresh_path(cam, ps, wl.fp.new_base + (pos - wl.queued), o, d, draws, time);
+        ps.fresh_draws[pos - wl.queued] = draws < 256u ? (uint8_t)draws : (uint8_t)0u;  // for the shading kernel
     } else {
         const float4 ro = ps.ray_o[wl.parity][pos], rd = ps.ray_d[wl.parity][pos];
         o = mk3(ro.x, ro.y, ro.z);
@@ -387,6 +398,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera 
         if (active) {
             uint32_t draws;
             fresh_path(cam, ps, fp.new_base + i, o, d, draws, time);
+            ps.fresh_draws[i] = draws < 256u ? (uint8_t)draws : (uint8_t)0u;  // for the shading kernel
         }
         TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
         const bool plain = sc.boxes_finite != 0u && __ballot(active && !ray_is_plain(r)) == 0ull;
@@ -589,7 +601,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene &sc, const DevCamera
     out.alive = out.shadow = false;
     if (wl.fresh(pos)) {  // the camera ray is not stored anywhere: src/camera.rs:207-210 with the path's own generator again
         float time;
-        fresh_path(cam, ps, slot, ro, rd, rng_counter, time);
+        fresh_path(cam, ps, slot, ro, rd, rng_counter, time, ps.fresh_draws[pos - wl.queued]);
         depth = cam.max_depth;
         b4 = make_float4(1.0f, 1.0f, 1.0f, time);
     } else {

@@ -146,6 +146,8 @@ struct PathState {
     uint32_t *ray_queue[2];             // [parity][position]: slot of the path; max_ray_chunks * QUEUE_CHUNK entries each
     float4 *hit;      // [work-list position]: t, u, v, global primitive index (bits)
     uint32_t *hit2;   // type | (instance+1) << 2, or PTD_HIT_MISS
+    uint8_t *fresh_draws;  // [index among the step's fresh paths]: draws the camera ray consumed (0: not recorded), so that
+                           // whoever needs the ray again can go straight to the draws that made it
     float4 *contrib;  // [slot]: radiance of the finished path (xyz); zero between uses
     uint32_t *shade_queue[MAX_QUEUES];  // work-list positions by material type; only the queues of types in use exist
     uint32_t *ctl;                      // CTL_WORDS control words

@@ -1090,6 +1090,7 @@ static int alloc_path_state(pt_context *ctx, std::vector<std::pair<void *, size_
     }
     if ((rc = dev_alloc(ctx, pool, &ps.hit, positions + n_fresh))) return rc;
     if ((rc = dev_alloc(ctx, pool, &ps.hit2, positions + n_fresh))) return rc;
+    if ((rc = dev_alloc(ctx, pool, &ps.fresh_draws, n_fresh + 1u))) return rc;
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, pool, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
     if ((rc = dev_alloc(ctx, pool, &ps.ctl, (size_t)CTL_WORDS))) return rc;
