@@ -250,3 +250,27 @@ def test_accumulator_identical_however_early_the_last_paths_of_a_batch_are_finis
             ref = acc
         else:
             assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"rolling={rolling} ticks={ticks}"
+
+
+def test_batch_length_is_learnt_from_the_first_drain():
+    # A scene whose paths end quickly at a depth limit of 50: the first drain shows that nearly nothing is left
+    # after a dozen launches, and the per-path sums shrink from 50 regions to that many (PT_OPT_BATCH_TICKS = 0,
+    # the default); with 1 they keep max_depth regions.  Same bits either way.
+    from pathtracer_amd.core import PT_OPT_BATCH_TICKS, PT_OPT_ROLLING
+    src = scenes.knob(width=128, spp=64, max_depth=50, detail=0.2)
+    out = {}
+    for ticks in (1, 0):
+        r = _renderer(src)
+        r.set_option(PT_OPT_ROLLING, 4 * 128 * 128)
+        r.set_option(PT_OPT_BATCH_TICKS, ticks)
+        r.render(0, 24, seed=2)
+        r.sync()
+        before = r.stats()["device_bytes"]
+        r.render(24, 64, seed=2)
+        acc, n = r.read_accum()
+        out[ticks] = (acc, before, r.stats()["device_bytes"])
+        assert n == 64
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    regions_bytes = 16 * 4 * 128 * 128  # one region of sums
+    assert out[1][1] - out[0][1] >= 20 * regions_bytes, (out[1][1], out[0][1])  # at least 20 of the 50 regions were given back
+    assert out[1][2] == out[1][1]  # nothing changes where max_depth is asked for
