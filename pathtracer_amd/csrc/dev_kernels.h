@@ -241,6 +241,7 @@ __device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bo
         const uint32_t parity = bounce & 1u;
         ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
         ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
+        for (uint32_t l = 0; l < PACKET_LISTS; l++) ps.ctl[(CTL_PACKET_CURSOR + PACKET_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
         if (n_chunks + n_new) atomicAdd(&stats->extend_nonempty, 1ull);
         if (n_new) {  // the paths that start with this launch, and their camera rays
             atomicAdd(&stats->paths_total, (unsigned long long)n_new);
@@ -385,7 +386,38 @@ __global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera 
     }
     shade_push_init();
     const uint32_t n_pieces = (fp.n_new + 63u) / 64u;
-    for (uint32_t piece = wave_index(); piece < n_pieces; piece += wave_count()) {
+#ifndef PT_PACKET_CLAIM
+#define PT_PACKET_CLAIM 2
+#endif
+    // Waves take the pieces as they get to them, in blocks of PT_PACKET_CLAIM (pieces differ in cost: sky against
+    // geometry, and the waves of this grid do not all start together beside the walking kernel).  Block b is on
+    // list b mod 8; a wave draws from the list of its XCD (a counter on a line of its own) and, when that is used
+    // up, from the next ones: all XCDs sweep the image together, so the waves of the whole chip work on
+    // neighbouring pixels at any one time and the hits reach the shading queues nearly in path order.
+    // Measured on a 184 k-triangle scene at 768x768 (closest-hit time of ten 256-strata steps): pieces dealt out in
+    // advance, wave w taking w, w + waves, ...: 266 ms; one shared counter, blocks of 32 / 8 / 4 / 2 pieces: 327 / 266 /
+    // 256 / 274 ms; a counter per XCD, blocks of 8 / 4 / 2 / 1: 264 / 253 / 249 / 250 ms; shading 97 -> 91 ms either way.
+    const uint32_t n_blocks = (n_pieces + (uint32_t)PT_PACKET_CLAIM - 1u) / (uint32_t)PT_PACKET_CLAIM;
+    uint32_t *cursors = &ps.ctl[(CTL_PACKET_CURSOR + PACKET_LISTS * wl.parity) * CTL_STRIDE];
+    uint32_t list = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % PACKET_LISTS;  // HW_REG_XCC_ID[3:0]
+    uint32_t lists_left = PACKET_LISTS;
+    uint32_t piece = 0u, piece_end = 0u;
+    for (;; piece++) {
+        if (piece == piece_end) {
+            uint32_t block = n_blocks;
+            while (lists_left != 0u) {
+                uint32_t got = 0u;
+                if (lane_id() == 0u) got = atomicAdd(&cursors[list * CTL_STRIDE], 1u);
+                block = (uint32_t)__builtin_amdgcn_readfirstlane((int)got) * PACKET_LISTS + list;
+                if (block < n_blocks) break;
+                block = n_blocks;
+                lists_left--;
+                list = (list + 1u) % PACKET_LISTS;
+            }
+            if (block >= n_blocks) break;
+            piece = block * (uint32_t)PT_PACKET_CLAIM;
+            piece_end = min(piece + (uint32_t)PT_PACKET_CLAIM, n_pieces);
+        }
         const uint32_t i = piece * 64u + lane_id();
         const bool active = i < fp.n_new;
         const uint32_t pos = wl.queued + i;

@@ -119,7 +119,9 @@ constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material
 constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
 constexpr uint32_t CTL_SHADOW_CHUNKS = 4 + 2 * MAX_QUEUES;  // +parity: chunks in the shadow-ray queue filled during a step of that parity
 constexpr uint32_t CTL_SHADOW_CURSOR = 6 + 2 * MAX_QUEUES;  // +parity: its pieces handed out so far
-constexpr uint32_t CTL_WORDS = (8 + 2 * MAX_QUEUES) * CTL_STRIDE;
+constexpr uint32_t CTL_PACKET_CURSOR = 8 + 2 * MAX_QUEUES;  // +8*parity+list: blocks of list `list` of the step's new paths handed out so far
+constexpr uint32_t PACKET_LISTS = 8;                       // one list per XCD: atomics of different XCDs go to different lines
+constexpr uint32_t CTL_WORDS = (8 + 2 * PACKET_LISTS + 2 * MAX_QUEUES) * CTL_STRIDE;
 
 // A launch may carry paths of several batches at once (each at a different bounce).  The slot
 // arrays are then cut into regions of region_cap slots, one batch per region, and a path's

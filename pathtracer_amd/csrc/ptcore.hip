@@ -75,6 +75,14 @@ struct pt_context {
 
     // scene
     bool have_scene = false, have_camera = false;
+    // Staging buffers of the query entry points (first hits, light pdfs, material probes, camera rays): kept from call
+    // to call and only ever grown, so that a caller that polls does not pay a hipMalloc / hipFree pair per call;
+    // a request above STAGE_KEEP bytes is served by an allocation of its own and given back at once.
+    static constexpr size_t STAGE_KEEP = 256u << 20;
+    struct Stage {
+        void *p = nullptr;
+        size_t bytes = 0;
+    } stage[3];
     std::vector<std::pair<void *, size_t>> scene_allocs;
     DevScene scene{};
     uint32_t n_queues = 0;
@@ -218,6 +226,49 @@ static void free_pool(pt_context *ctx, std::vector<std::pair<void *, size_t>> &p
     }
     pool.clear();
 }
+
+// Device memory of at least `bytes` for staging slot i of a query entry point; *transient: the caller frees it.
+static int stage_get(pt_context *ctx, int i, size_t bytes, void **out, bool *transient) {
+    pt_context::Stage &s = ctx->stage[i];
+    *transient = false;
+    if (bytes <= s.bytes) {
+        *out = s.p;
+        return PT_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    if (bytes > pt_context::STAGE_KEEP) {
+        *transient = true;
+    } else {
+        if (s.p) (void)hipFree(s.p);
+        ctx->device_bytes += bytes - s.bytes;
+        s.p = p;
+        s.bytes = bytes;
+    }
+    *out = p;
+    return PT_OK;
+}
+// Up to three staging buffers at once; put() gives back the ones that were too large to keep.
+struct Staging {
+    pt_context *ctx;
+    void *p[3] = {nullptr, nullptr, nullptr};
+    bool transient[3] = {false, false, false};
+    explicit Staging(pt_context *c) : ctx(c) {}
+    template <class T>
+    int get(int i, size_t count, T **out) {
+        void *q = nullptr;
+        int rc = stage_get(ctx, i, std::max<size_t>(count, 1) * sizeof(T), &q, &transient[i]);
+        if (rc) return rc;
+        p[i] = q;
+        *out = (T *)q;
+        return PT_OK;
+    }
+    ~Staging() {
+        for (int i = 0; i < 3; i++)
+            if (transient[i] && p[i]) (void)hipFree(p[i]);
+    }
+};
 
 // workgroups of a traversal kernel that fit a CU's 160 KB of LDS with their lane stacks
 constexpr int MAX_WALK_BLOCKS = 163840 / (LDS_LEVELS * BLOCK * 8 + 1024);
@@ -449,6 +500,8 @@ void pt_destroy(pt_context *ctx) {
     if (ctx->accum) (void)hipFree(ctx->accum);
     if (ctx->rgb8) (void)hipFree(ctx->rgb8);
     if (ctx->stats) (void)hipFree(ctx->stats);
+    for (auto &st : ctx->stage)
+        if (st.p) (void)hipFree(st.p);
     destroy_pipes(ctx);
     delete ctx;
 }
@@ -1168,7 +1221,8 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
             // paths the walking kernel runs with four; where the queued rays are the larger part it keeps five
             // (1 M-triangle box, interior: 0 to -3 % with four, knob: +9 %).
             const bool mostly_new = (uint64_t)fp.n_new >= queued;
-            const unsigned per_cu = mostly_new ? 16u : 8u;
+            // the camera-ray kernel hands its work out piece by piece, so its grid is what a CU can hold at once
+            const unsigned per_cu = 8u;
             const dim3 gp((unsigned)std::min<uint64_t>(((uint64_t)fp.n_new + BLOCK - 1) / BLOCK, (uint64_t)ctx->n_cu * per_cu));
 #define EXP(I, M) hipLaunchKernelGGL((k_extend_packet<I, M>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
             if (ctx->scene.n_moving != 0) {
@@ -1737,13 +1791,12 @@ int pt_generate_rays(pt_context *ctx, uint32_t stratum, uint64_t seed, float *ra
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const uint32_t npix = ctx->cam.width * ctx->cam.height;
     float *d = nullptr;
-    hipError_t e = hipMalloc((void **)&d, (size_t)npix * 8 * sizeof(float));
-    if (e != hipSuccess) return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
+    Staging stg(ctx);
+    if ((rc = stg.get(0, (size_t)npix * 8, &d))) return rc;
     BatchParams bp{mix64_host(seed), stratum, 1u, npix, npix, ctx->bsdf_prob};
     hipLaunchKernelGGL(k_raygen_only, dim3(grid_for(ctx, npix)), dim3(BLOCK), 0, ctx->stream, ctx->cam, bp, d);
-    e = hipMemcpyAsync(rays, d, (size_t)npix * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemcpyAsync(rays, d, (size_t)npix * 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_generate_rays: %s", hipGetErrorString(e));
     return PT_OK;
 }
@@ -1762,14 +1815,10 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
     with_moving = with_moving && ctx->scene.n_moving != 0;
     float *d_rays = nullptr, *d_times = nullptr;
     pt_hit *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_rays, n * 8 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(pt_hit));
-    if (e == hipSuccess && with_moving && times) e = hipMalloc((void **)&d_times, n * sizeof(float));
-    if (e != hipSuccess) {
-        if (d_rays) (void)hipFree(d_rays);
-        if (d_out) (void)hipFree(d_out);
-        return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    }
+    Staging stg(ctx);
+    if ((rc = stg.get(0, n * 8, &d_rays)) || (rc = stg.get(1, n, &d_out))) return rc;
+    if (with_moving && times && (rc = stg.get(2, n, &d_times))) return rc;
+    hipError_t e;
     hipStream_t st = ctx->stream;
     e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess && d_times) e = hipMemcpyAsync(d_times, times, n * sizeof(float), hipMemcpyHostToDevice, st);
@@ -1793,9 +1842,6 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFree(d_rays);
-    (void)hipFree(d_out);
-    if (d_times) (void)hipFree(d_times);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
     return sync_all(ctx);
 }
@@ -1897,12 +1943,10 @@ int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_sol
     if (ctx->scene.n_light_total == 0) return fail(ctx, PT_ERR_STATE, "the scene has no lights");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *d_rays = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_rays, n * 8 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof(float));
-    if (e != hipSuccess) {
-        if (d_rays) (void)hipFree(d_rays);
-        return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    }
+    Staging stg(ctx);
+    int rc;
+    if ((rc = stg.get(0, n * 8, &d_rays)) || (rc = stg.get(1, n, &d_out))) return rc;
+    hipError_t e;
     hipStream_t st = ctx->stream;
     e = hipMemcpyAsync(d_rays, rays, n * 8 * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
@@ -1911,8 +1955,6 @@ int pt_light_pdf(pt_context *ctx, const float *rays, uint64_t n, int tris_by_sol
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFree(d_rays);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_light_pdf: %s", hipGetErrorString(e));
     return PT_OK;
 }
@@ -1927,12 +1969,10 @@ int pt_material_probe(pt_context *ctx, int32_t material, uint64_t seed, const pt
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     pt_material_probe_in *d_in = nullptr;
     pt_material_probe_out *d_out = nullptr;
-    hipError_t e = hipMalloc((void **)&d_in, n * sizeof *d_in);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * sizeof *d_out);
-    if (e != hipSuccess) {
-        if (d_in) (void)hipFree(d_in);
-        return fail(ctx, PT_ERR_NOMEM, "hipMalloc: %s", hipGetErrorString(e));
-    }
+    Staging stg(ctx);
+    int rc;
+    if ((rc = stg.get(0, n, &d_in)) || (rc = stg.get(1, n, &d_out))) return rc;
+    hipError_t e;
     hipStream_t st = ctx->stream;
     e = hipMemcpyAsync(d_in, in, n * sizeof *d_in, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
@@ -1941,8 +1981,6 @@ int pt_material_probe(pt_context *ctx, int32_t material, uint64_t seed, const pt
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_material_probe: %s", hipGetErrorString(e));
     return PT_OK;
 }

@@ -56,3 +56,27 @@ def test_per_sample_radiance(name):
     # libm differences (sin/cos/pow within an ulp or two) may flip a rare branch; almost all paths agree
     assert close.mean() > 0.995, close.mean()
     assert abs(got.mean() - ref.mean()) <= 0.01 * max(ref.mean(), 1e-6)
+
+
+def test_query_calls_of_changing_size_reuse_their_staging_buffers():
+    """The query entry points keep their device staging buffers between calls (grown, never shrunk): a smaller call
+    after a larger one, and a larger one after that, return what a fresh context returns, and the memory the
+    context reports only grows by the largest request."""
+    src = scenes.small_mixed(96, 16)
+    o, r = _pair(src)
+    rays = o.primary_rays()
+    ids, tuv = o.trace(rays)
+    base = r.stats()["device_bytes"]
+    sizes = [len(rays), 257, 1, len(rays) // 2, len(rays)]
+    seen = []
+    for n in sizes:
+        h = r.trace(rays[:n])
+        assert np.array_equal(h["prim_type"], ids[:n, 0]) and np.array_equal(h["prim_id"], ids[:n, 1])
+        hit = ids[:n, 0] >= 0
+        assert bits_equal(h["t"][hit], tuv[:n][hit, 0])
+        seen.append(r.stats()["device_bytes"])
+    assert seen[0] > base and all(s == seen[0] for s in seen[1:]), (base, seen)
+    # camera rays use the same buffers
+    ro, _ = o.sample_rays(seed=7, stratum=3)
+    assert bits_equal(ro, r.generate_rays(3, seed=7))
+    assert bits_equal(ro, r.generate_rays(3, seed=7))
