@@ -407,3 +407,106 @@ def test_camera_constants_lucy():
     viewport_u = 2.0 * h * 10.0 * (1200.0 / 675.0)
     assert np.allclose(k[8:11], u * viewport_u / 1200.0, rtol=2e-6, atol=1e-9)
     assert abs(k[22] - 1.0 / 226.0) < 1e-9
+
+
+# ---------------------------------------------------------------- the simple materials and the lights by hand
+def _unit_draws(seed, pixel, stratum, n):
+    """gen_range(0.0..1.0) of rand 0.8.5 on the oracle's generator: the top 23 bits of the upper half of a draw."""
+    return [float((int(d) >> 32) >> 9) / 8388608.0 for d in po.rng_draws(seed, pixel, stratum, n)]
+
+
+def _simple_rig():
+    s = SceneSource()
+    m = {"mirror": s.metal((0.8, 0.85, 0.88), 0.0), "brushed": s.metal((0.5, 0.5, 0.5), 0.3), "too_fuzzy": s.metal((1, 1, 1), 7.0),
+         "glass": s.dielectric(1.5), "lamp": s.diffuse_light((4.0, 3.0, 2.0))}
+    for k, mat in enumerate(m.values()):
+        s.objects.add_quad((2.0 * k, 0, 0), (1, 0, 0), (0, 1, 0), mat)
+    s.camera = CameraSrc(1.0, 8, 40.0, (0, 0, -5), (0, 0, 0), 1.0, 0.0, 4, 4, (0, 0, 0))
+    return po.OracleScene(s), m
+
+
+def test_metal_mirror_and_fuzz_from_the_positive_quadrant():
+    o, m = _simple_rig()
+    # metal.rs:31-47 in the shading frame (normal = +y): reflect_y(-normalize(w_out)) flips y back; fuzz 0 draws nothing
+    w, n = o.material_scatter(m["mirror"], (1.2, 1.6, 0.0), seed=1, pixel=2, stratum=3)
+    assert n == 0 and np.allclose(w, [-0.6, 0.8, 0.0], atol=1e-7)
+    bsdf, _, em = o.material_eval(m["mirror"], (0.6, 0.8, 0.0), (-0.6, 0.8, 0.0))
+    assert np.allclose(bsdf, [0.8, 0.85, 0.88]) and not em.any()   # bsdf_evaluate is the albedo (:49-56)
+    # fuzz > 0: fuzz * normalize(SpherePDF::generate) is added.  generate (types/pdf.rs:25-37) draws (u, v) from
+    # [0, 1)^2 -- the positive quadrant only -- until u^2 + v^2 <= 1 and returns (2u s, 2v s, 1 - 2 n2), s = sqrt(1 - n2)
+    for fuzz_name, fuzz in (("brushed", 0.3), ("too_fuzzy", 1.0)):  # Metal::new clamps fuzz to [0, 1] (:14-18)
+        for pixel in range(8):
+            d = _unit_draws(5, pixel, 1, 8)
+            used = 0
+            while True:
+                u, v = d[used], d[used + 1]
+                used += 2
+                if u * u + v * v <= 1.0:
+                    break
+            n2 = u * u + v * v
+            g = np.array([2 * u * math.sqrt(1 - n2), 2 * v * math.sqrt(1 - n2), 1 - 2 * n2])
+            want = np.array([-0.6, 0.8, 0.0]) + fuzz * g / np.linalg.norm(g)
+            w, n = o.material_scatter(m[fuzz_name], (0.6, 0.8, 0.0), seed=5, pixel=pixel, stratum=1)
+            assert n == used and np.allclose(w, want, atol=2e-6)
+            assert w[0] >= -0.6 - 1e-6 and w[1] >= 0.8 - 1e-6  # the offset never points to -x or -y
+
+
+def test_dielectric_reflects_by_the_disney_fresnel_term():
+    o, m = _simple_rig()
+    # dielectric.rs:36-57: the Schlick value is computed and then replaced by fresnel_o(unit_direction, +y, ri);
+    # one draw decides.  Normal incidence from outside: ri = 1/1.5 and F = ((1-e)/(1+e))^2/2 + ((e-1)/(2e))^2/2, e = 1.5
+    f = 0.5 * ((0.5 / 2.5) ** 2 + (0.5 / 3.0) ** 2)
+    assert abs(po.fresnel_o((0, -1, 0), (0, 1, 0), 1 / 1.5) - f) < 1e-7
+    assert abs(f - 0.04) > 5e-3  # not Schlick's r0
+    reflected = 0
+    for pixel in range(64):
+        (u,) = _unit_draws(11, pixel, 0, 1)
+        w, n = o.material_scatter(m["glass"], (0, 2, 0), seed=11, pixel=pixel, stratum=0, front_face=True)
+        assert n == 1
+        assert np.allclose(w, [0, 1, 0] if f > u else [0, -1, 0], atol=1e-7)
+        reflected += f > u
+    assert 0 < reflected < 16  # F is about 3.4 %
+    # from inside at 60 degrees: ri = 1.5, 1.5 sin > 1, total internal reflection whatever the draw
+    for pixel in range(8):
+        w, n = o.material_scatter(m["glass"], (math.sqrt(0.75), 0.5, 0), seed=11, pixel=pixel, stratum=0, front_face=False)
+        assert n == 1 and np.allclose(w, [-math.sqrt(0.75), 0.5, 0.0], atol=1e-6)
+    # from inside at 30 degrees: refracts away from the normal, sin_t = 1.5 * 0.5, unless the draw reflects
+    (u,) = _unit_draws(11, 0, 0, 1)
+    f_in = po.fresnel_o((-0.5, -math.sqrt(0.75), 0), (0, 1, 0), 1.5)
+    w, _ = o.material_scatter(m["glass"], (0.5, math.sqrt(0.75), 0), seed=11, pixel=0, stratum=0, front_face=False)
+    want = [-0.5, math.sqrt(0.75), 0] if f_in > u else [-0.75, -math.sqrt(1 - 0.75 ** 2), 0]
+    assert np.allclose(w, want, atol=1e-6)
+    bsdf, _, _ = o.material_eval(m["glass"], (0, 1, 0), (0, -1, 0))
+    assert bsdf.tolist() == [1, 1, 1]  # :59-66
+
+
+def test_diffuse_light_emits_from_its_front_face_only():
+    o, m = _simple_rig()
+    _, _, em = o.material_eval(m["lamp"], (0, 1, 0), (0, 1, 0), front_face=True)
+    assert em.tolist() == [4.0, 3.0, 2.0]
+    _, _, em = o.material_eval(m["lamp"], (0, 1, 0), (0, 1, 0), front_face=False)  # light.rs:42-47
+    assert em.tolist() == [0.0, 0.0, 0.0]
+
+
+def test_light_pdfs_of_a_sphere_and_of_a_triangle():
+    # Sphere::pdf (objects/sphere.rs:108-119): 1 / (2 pi (1 - sqrt(1 - r^2 / d^2))) when the ray hits, else 0
+    def sphere_light(s):
+        lamp = s.diffuse_light((1, 1, 1))
+        s.objects.add_sphere((0, 5, 0), 1.0, lamp)
+        s.lights.add_sphere((0, 5, 0), 1.0, lamp)
+    o = _scene(sphere_light)
+    want = 1.0 / (2 * math.pi * (1 - math.sqrt(1 - 1.0 / 25.0)))
+    assert abs(o.light_pdf((0, 0, 0), (0, 1, 0)) - want) < 2e-5 * want   # 1 - cos cancels four digits in f32
+    assert abs(o.light_pdf((0, 0, 0), (0.19, 0.98, 0)) - want) < 2e-5 * want   # anywhere inside the cone: same value
+    assert o.light_pdf((0, 0, 0), (0.21, 0.97, 0)) == 0.0   # sin of the cone's half angle is 0.2
+    # Triangle::pdf (objects/tri_mesh.rs:252-261): 2 / |e1 x e2| = 1 / area for a ray that hits, wherever it comes from --
+    # a density over the triangle, not over directions; LightBuffer::pdf (objects.rs:259-278) averages over the lights
+    def two_lights(s):
+        lamp = s.diffuse_light((1, 1, 1))
+        tri = np.array([[[0, 4, 0], [3, 4, 0], [0, 4, 2]]], np.float32)   # area 3
+        s.lights.add_triangles(tri, material=lamp)
+        s.lights.add_sphere((20, 5, 0), 1.0, lamp)
+    o = _scene(two_lights)
+    assert abs(o.light_pdf((0.5, 0, 0.5), (0, 1, 0)) - 0.5 * (1.0 / 3.0)) < 1e-7
+    assert abs(o.light_pdf((0.5, -40, 0.5), (0, 1, 0)) - 0.5 * (1.0 / 3.0)) < 1e-7   # ten times as far: the same
+    assert abs(o.light_pdf((20, 0, 0), (0, 1, 0)) - 0.5 * want) < 2e-5 * want
