@@ -2106,3 +2106,15 @@ int pt_stats_reset(pt_context *ctx) {
     return PT_OK;
 }
 
+
+#ifdef PT_WALK_STATS
+// Debug build only: the lane-occupancy totals of the walking kernels since the last reset (tools/walk_stats.py).
+extern "C" int ptc_debug_walk_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ptd::g_walk_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ptd::g_walk_stats), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
