@@ -1,14 +1,15 @@
 #!/bin/bash
-# PT_OPT_REFILL_BELOW x PT_OPT_LEAF_BATCH of the walking kernel on a scene whose rays are mostly bounce rays
+# PT_OPT_REFILL_BELOW x PT_OPT_LEAF_BATCH of the walking kernel: SCENE, W and BENCH_ARGS choose the workload
 mkdir -p gpurun_out
 SCENE=${SCENE:-dragon_box}; W=${W:-1024}
-for cfg in "32 16" "40 16" "48 16" "56 16" "48 24" "40 24" "32 24" "48 12"; do
-  set -- $cfg
-  timeout -k 10 200 python bench.py --no-cpu-baseline --scene $SCENE --width $W --refill-below $1 --leaf-batch $2 $BENCH_ARGS > gpurun_out/rf_$1_$2.json 2> gpurun_out/rf_$1_$2.err || { echo "$cfg failed"; tail -3 gpurun_out/rf_$1_$2.err; exit 1; }
-  python3 - "$1" "$2" <<'PY'
+CFGS=${CFGS:-32_16 40_16 48_16 32_24 40_24 32_12 24_16}
+for cfg in $CFGS; do
+  a=${cfg%%_*}; b=${cfg##*_}
+  timeout -k 10 200 python bench.py --no-cpu-baseline --scene $SCENE --width $W --refill-below $a --leaf-batch $b $BENCH_ARGS > gpurun_out/rf_${a}_$b.json 2> gpurun_out/rf_${a}_$b.err || { echo "$cfg failed"; tail -3 gpurun_out/rf_${a}_$b.err; exit 1; }
+  python3 - "$a" "$b" "$SCENE" <<'PY'
 import json,sys
-a,b=sys.argv[1:3]
+a,b,sc=sys.argv[1:4]
 d=json.loads(open(f"gpurun_out/rf_{a}_{b}.json").read().strip().splitlines()[-1])
-print(a,b, round(d["value"]), "Mrays/s", {k:round(v,1) for k,v in d["kernel_ms"].items()}, flush=True)
+print(sc,a,b, round(d["value"]), "Mrays/s", {k:round(v,1) for k,v in d["kernel_ms"].items()}, flush=True)
 PY
 done
