@@ -60,6 +60,7 @@ pub const PT_OPT_INTEGRATOR: i32 = 12;
 pub const PT_OPT_LIVE_FACTOR: i32 = 13;
 pub const PT_OPT_PACKET: i32 = 14;
 pub const PT_OPT_BATCH_TICKS: i32 = 15;
+pub const PT_OPT_SHADE_CLAIM: i32 = 16;
 
 /// One `FlatBVHNode` (`src/bvh.rs:667-679`) in 32 bytes.
 #[repr(C)]

@@ -201,6 +201,11 @@ enum {
                                            what the first drain of the pipeline shows about how fast this scene's paths
                                            end (a handful of paths left, at least 8 launches); 1: always
                                            max_depth; >= 2: that many.  Same results for any value */
+    PT_OPT_SHADE_CLAIM = 16,            /* how the shading kernels share out their queues: 0: wave w takes the pieces w, w + waves, ...;
+                                           n in 1..64: waves draw blocks of n 256-entry chunks as they get to them, from a
+                                           counter per XCD; -1 (default): chosen step by step, 0 where most of a step's
+                                           vertices are first hits (queued in path order already), for queues of fewer
+                                           than 2048 chunks and in scenes with more than four material types, 4 elsewhere.  Same results for any value */
     PT_OPT_LIVE_FACTOR = 13             /* rolling schedule: rays in flight a pipe has room for, as a multiple of the paths
                                            started per launch (at least 2, at most max_depth; default 4).  A batch starts
                                            only when its paths fit beside the rays in flight, so a scene whose paths live

@@ -22,7 +22,7 @@ _host: Optional[C.CDLL] = None
 PT_NODE_LEAF = 0x80000000
 (PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_MAX_PATHS, PT_OPT_PROFILE, PT_OPT_COUNTERS, PT_OPT_TRAVERSAL, PT_OPT_PIPES,
  PT_OPT_REFILL_BELOW, PT_OPT_LEAF_BATCH, PT_OPT_BLOCKS_PER_CU, PT_OPT_TAIL_BELOW, PT_OPT_ROLLING, PT_OPT_DEVICE_BVH, PT_OPT_INTEGRATOR,
- PT_OPT_LIVE_FACTOR, PT_OPT_PACKET, PT_OPT_BATCH_TICKS) = range(16)
+ PT_OPT_LIVE_FACTOR, PT_OPT_PACKET, PT_OPT_BATCH_TICKS, PT_OPT_SHADE_CLAIM) = range(17)
 
 
 class PtError(RuntimeError):

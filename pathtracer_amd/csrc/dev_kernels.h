@@ -46,14 +46,34 @@ __device__ __forceinline__ void path_sample(const PathState &ps, uint32_t slot, 
     seed_mixed = rp.seed_mixed;
 }
 
-// Consumer side of a chunked queue with a fixed share per wave: wave w takes the 64-entry
-// pieces w, w + waves, ... of the chunks in use.
-struct PieceWalk {
-    uint32_t piece, n_pieces, step;
+// Work handed out as the waves get to it.  Block b of the work is on list b mod WORK_LISTS; a wave draws from the
+// list of its XCD (a counter on a line of its own) and, when that is used up, from the next ones.  All XCDs
+// sweep the work together from its start to its end, whatever the number of workgroups a CU holds at once and
+// whenever they start: what is read and written at any one time lies close together, and results are appended
+// to the queues nearly in the order of the work.  `cursors`: WORK_LISTS control words, CTL_STRIDE apart, zero
+// before the launch.
+struct BlockClaim {
+    uint32_t *cursors;
+    uint32_t n_blocks, list, lists_left;
+    __device__ __forceinline__ void init(uint32_t *c, uint32_t n) {
+        cursors = c;
+        n_blocks = n;
+        list = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % WORK_LISTS;  // HW_REG_XCC_ID[3:0]
+        lists_left = WORK_LISTS;
+    }
+    // the next block for this wave (the same value in every lane); false when the work is used up
+    __device__ __forceinline__ bool next(uint32_t &block) {
+        while (lists_left != 0u) {
+            uint32_t got = 0u;
+            if (lane_id() == 0u) got = atomicAdd(&cursors[list * CTL_STRIDE], 1u);
+            block = (uint32_t)__builtin_amdgcn_readfirstlane((int)got) * WORK_LISTS + list;
+            if (block < n_blocks) return true;
+            lists_left--;
+            list = (list + 1u) % WORK_LISTS;
+        }
+        return false;
+    }
 };
-__device__ __forceinline__ PieceWalk piece_walk(uint32_t n_chunks) {
-    return PieceWalk{wave_index(), n_chunks * (QUEUE_CHUNK / 64u), wave_count()};
-}
 
 // Open chunks of the material queues, one set per wave of the workgroup, kept in LDS
 // because their number is only known at run time.  Only the owning wave touches its row.
@@ -241,7 +261,7 @@ __device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bo
         const uint32_t parity = bounce & 1u;
         ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
         ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        for (uint32_t l = 0; l < PACKET_LISTS; l++) ps.ctl[(CTL_PACKET_CURSOR + PACKET_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
+        for (uint32_t l = 0; l < WORK_LISTS; l++) ps.ctl[(CTL_PACKET_CURSOR + WORK_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
         if (n_chunks + n_new) atomicAdd(&stats->extend_nonempty, 1ull);
         if (n_new) {  // the paths that start with this launch, and their camera rays
             atomicAdd(&stats->paths_total, (unsigned long long)n_new);
@@ -389,32 +409,18 @@ __global__ __launch_bounds__(BLOCK) void k_extend_packet(DevScene sc, DevCamera 
 #ifndef PT_PACKET_CLAIM
 #define PT_PACKET_CLAIM 2
 #endif
-    // Waves take the pieces as they get to them, in blocks of PT_PACKET_CLAIM (pieces differ in cost: sky against
-    // geometry, and the waves of this grid do not all start together beside the walking kernel).  Block b is on
-    // list b mod 8; a wave draws from the list of its XCD (a counter on a line of its own) and, when that is used
-    // up, from the next ones: all XCDs sweep the image together, so the waves of the whole chip work on
-    // neighbouring pixels at any one time and the hits reach the shading queues nearly in path order.
+    // Waves take the pieces as they get to them, in blocks of PT_PACKET_CLAIM (BlockClaim): pieces differ in cost,
+    // sky against geometry, and the waves of this grid do not all start together beside the walking kernel.
     // Measured on a 184 k-triangle scene at 768x768 (closest-hit time of ten 256-strata steps): pieces dealt out in
     // advance, wave w taking w, w + waves, ...: 266 ms; one shared counter, blocks of 32 / 8 / 4 / 2 pieces: 327 / 266 /
     // 256 / 274 ms; a counter per XCD, blocks of 8 / 4 / 2 / 1: 264 / 253 / 249 / 250 ms; shading 97 -> 91 ms either way.
-    const uint32_t n_blocks = (n_pieces + (uint32_t)PT_PACKET_CLAIM - 1u) / (uint32_t)PT_PACKET_CLAIM;
-    uint32_t *cursors = &ps.ctl[(CTL_PACKET_CURSOR + PACKET_LISTS * wl.parity) * CTL_STRIDE];
-    uint32_t list = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % PACKET_LISTS;  // HW_REG_XCC_ID[3:0]
-    uint32_t lists_left = PACKET_LISTS;
+    BlockClaim claim;
+    claim.init(&ps.ctl[(CTL_PACKET_CURSOR + WORK_LISTS * wl.parity) * CTL_STRIDE], (n_pieces + (uint32_t)PT_PACKET_CLAIM - 1u) / (uint32_t)PT_PACKET_CLAIM);
     uint32_t piece = 0u, piece_end = 0u;
     for (;; piece++) {
         if (piece == piece_end) {
-            uint32_t block = n_blocks;
-            while (lists_left != 0u) {
-                uint32_t got = 0u;
-                if (lane_id() == 0u) got = atomicAdd(&cursors[list * CTL_STRIDE], 1u);
-                block = (uint32_t)__builtin_amdgcn_readfirstlane((int)got) * PACKET_LISTS + list;
-                if (block < n_blocks) break;
-                block = n_blocks;
-                lists_left--;
-                list = (list + 1u) % PACKET_LISTS;
-            }
-            if (block >= n_blocks) break;
+            uint32_t block;
+            if (!claim.next(block)) break;
             piece = block * (uint32_t)PT_PACKET_CLAIM;
             piece_end = min(piece + (uint32_t)PT_PACKET_CLAIM, n_pieces);
         }
@@ -703,8 +709,25 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevCamera cam, Pat
     next.init();
     shadows.init();
     uint32_t survivors = 0u, shadow_rays = 0u;
-    const PieceWalk pw = piece_walk(n_chunks);
-    for (uint32_t piece = pw.piece; piece < pw.n_pieces; piece += pw.step) {
+    // The queue's pieces either dealt out in advance (ps.shade_claim == 0: wave w takes w, w + waves, ...) or drawn in
+    // blocks of ps.shade_claim chunks as the waves get to them (BlockClaim).  The host chooses per step: where most
+    // vertices are first hits, already queued in path order, dealing in advance is 9 % faster; where most belong to
+    // later bounces, drawing is (8 % on 1 M triangles in a box).
+    constexpr uint32_t CHUNK_PIECES = QUEUE_CHUNK / 64u;
+    const uint32_t n_pieces = n_chunks * CHUNK_PIECES, claim_chunks = n_chunks >= ps.shade_claim_from ? ps.shade_claim : 0u;
+    BlockClaim claim;
+    claim.init(&ps.ctl[(CTL_SHADE_CURSOR + WORK_LISTS * (2u * q + parity)) * CTL_STRIDE], claim_chunks ? (n_chunks + claim_chunks - 1u) / claim_chunks : 0u);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (uint32_t l = 0; l < WORK_LISTS; l++) ps.ctl[(CTL_SHADE_CURSOR + WORK_LISTS * (2u * q + (parity ^ 1u)) + l) * CTL_STRIDE] = 0u;
+    uint32_t piece = wave_index(), piece_end = claim_chunks ? piece : n_pieces;
+    const uint32_t piece_step = claim_chunks ? 1u : wave_count();
+    for (;; piece += piece_step) {
+        if (piece >= piece_end) {
+            uint32_t block;
+            if (claim_chunks == 0u || !claim.next(block)) break;
+            piece = block * claim_chunks * CHUNK_PIECES;
+            piece_end = min(piece + claim_chunks * CHUNK_PIECES, n_pieces);
+        }
         const uint32_t pos = queue[(size_t)piece * 64u + lane_id()];
         VertexOut v;
         v.alive = v.shadow = false;

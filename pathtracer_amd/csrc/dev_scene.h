@@ -119,9 +119,10 @@ constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material
 constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
 constexpr uint32_t CTL_SHADOW_CHUNKS = 4 + 2 * MAX_QUEUES;  // +parity: chunks in the shadow-ray queue filled during a step of that parity
 constexpr uint32_t CTL_SHADOW_CURSOR = 6 + 2 * MAX_QUEUES;  // +parity: its pieces handed out so far
+constexpr uint32_t WORK_LISTS = 8;  // lists of work blocks, one per XCD: atomics of different XCDs go to different lines
 constexpr uint32_t CTL_PACKET_CURSOR = 8 + 2 * MAX_QUEUES;  // +8*parity+list: blocks of list `list` of the step's new paths handed out so far
-constexpr uint32_t PACKET_LISTS = 8;                       // one list per XCD: atomics of different XCDs go to different lines
-constexpr uint32_t CTL_WORDS = (8 + 2 * PACKET_LISTS + 2 * MAX_QUEUES) * CTL_STRIDE;
+constexpr uint32_t CTL_SHADE_CURSOR = CTL_PACKET_CURSOR + 2 * WORK_LISTS;  // +8*(2*queue+parity)+list: chunk blocks of that list of material queue [queue] handed out
+constexpr uint32_t CTL_WORDS = (8 + 2 * MAX_QUEUES + 2 * WORK_LISTS + 2 * WORK_LISTS * MAX_QUEUES) * CTL_STRIDE;
 
 // A launch may carry paths of several batches at once (each at a different bounce).  The slot
 // arrays are then cut into regions of region_cap slots, one batch per region, and a path's
@@ -164,6 +165,8 @@ struct PathState {
     uint32_t n_slots;
     int refill_below;          // a traversing wave with fewer busy lanes than this goes back for more rays
     int leaf_batch;            // lanes that must be waiting at a leaf before the wave runs a primitive test
+    uint32_t shade_claim;      // shading kernels: 0 = wave w takes pieces w, w + waves, ...; n = waves draw blocks of n chunks as they get to them
+    uint32_t shade_claim_from; // ... where the queue has at least this many chunks (a short queue is not worth eight counters)
     RegionParams *regions;     // [slots / region_cap] the batches the regions hold
     uint32_t region_cap;       // slots per region
     // next-event estimation (PT_OPT_INTEGRATOR = 1): a vertex may leave a shadow ray behind; if it reaches an

@@ -59,6 +59,7 @@ struct pt_context {
     int blocks_per_cu = 5;  // as many as the LDS stacks allow: measured 0.4 - 4 % faster than 4 on every scene
 #endif
     int refill_below = 32, leaf_batch = 16, shade_blocks_per_cu = 8;
+    int shade_claim = -1;  // PT_OPT_SHADE_CLAIM
     bool nee = false;  // PT_OPT_INTEGRATOR = 1: next-event estimation (shade_vertex)
     uint32_t device_bvh_min = 0;  // triangle buffers that come without nodes and have at least this many triangles get their BVH built on the device (0: never)
     double live_factor = 4.0;  // PT_OPT_LIVE_FACTOR
@@ -586,6 +587,10 @@ int pt_set_option(pt_context *ctx, int key, double value) {
         case PT_OPT_BATCH_TICKS:
             if (!(value >= 0.0 && value <= 1.0e6) || value != (double)(uint32_t)value) return fail(ctx, PT_ERR_INVALID, "batch ticks must be a count");
             ctx->batch_ticks = (uint32_t)value;
+            return PT_OK;
+        case PT_OPT_SHADE_CLAIM:
+            if (!(value >= -1.0 && value <= 64.0) || value != (double)(int)value) return fail(ctx, PT_ERR_INVALID, "shade claim must be -1, 0 or a number of chunks up to 64");
+            ctx->shade_claim = (int)value;
             return PT_OK;
         case PT_OPT_LIVE_FACTOR:
             if (!(value >= 2.0 && value <= 1.0e6)) return fail(ctx, PT_ERR_INVALID, "live factor must be at least 2");
@@ -1167,6 +1172,8 @@ static int alloc_path_state(pt_context *ctx, std::vector<std::pair<void *, size_
     if ((rc = dev_alloc(ctx, pool, &ps.overflow, (size_t)extra * ps.overflow_stride))) return rc;
     ps.refill_below = ctx->refill_below;
     ps.leaf_batch = ctx->leaf_batch;
+    ps.shade_claim = 0u;
+    ps.shade_claim_from = 0u;
     ps.n_slots = (uint32_t)n_slots;
     return PT_OK;
 }
@@ -1380,6 +1387,8 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
     pp.ps.region_cap = (uint32_t)n_slots;  // one region: the batch
     pp.ps.refill_below = ctx->refill_below;
     pp.ps.leaf_batch = ctx->leaf_batch;
+    pp.ps.shade_claim = ctx->shade_claim > 0 ? (uint32_t)ctx->shade_claim : 0u;  // chosen step by step only by the rolling schedule
+    pp.ps.shade_claim_from = 0u;
     const PathState ps = pp.ps;
     RegionParams rp{};
     rp.seed_mixed = bp.seed_mixed;
@@ -1547,6 +1556,10 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
     r.ps.refill_below = ctx->refill_below;
     r.ps.leaf_batch = ctx->leaf_batch;
     r.ps.next_rays = r.tick_rays + ring;
+    // first hits arrive in path order: their queues are best dealt out in advance; the vertices of later bounces are not
+    // (nor are they where many material types share a step: 11 queues on three streams lose 12 % of the shading time to it)
+    r.ps.shade_claim = ctx->shade_claim >= 0 ? (uint32_t)ctx->shade_claim : ((nb && (uint64_t)nb->n_slots >= r.known_rays) || ctx->n_queues > 4u ? 0u : 4u);
+    r.ps.shade_claim_from = ctx->shade_claim >= 0 ? 0u : 2048u;
     const PathState ps = r.ps;
     const uint32_t depth = ctx->cam.max_depth;
     const uint32_t region = (uint32_t)(r.tick % r.n_regions), base = region * r.cap;
@@ -1914,6 +1927,8 @@ int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_
     ps.n_slots = (uint32_t)n;
     ps.refill_below = ctx->refill_below;
     ps.leaf_batch = ctx->leaf_batch;
+    ps.shade_claim = 0u;
+    ps.shade_claim_from = 0u;
     hipStream_t st = ctx->stream;
     // the array keeps what the last call on this GPU left in it: the control words start from zero
     HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, (size_t)CTL_WORDS * sizeof(uint32_t), st));

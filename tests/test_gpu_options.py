@@ -274,3 +274,28 @@ def test_batch_length_is_learnt_from_the_first_drain():
     regions_bytes = 16 * 4 * 128 * 128  # one region of sums
     assert out[1][1] - out[0][1] >= 20 * regions_bytes, (out[1][1], out[0][1])  # at least 20 of the 50 regions were given back
     assert out[1][2] == out[1][1]  # nothing changes where max_depth is asked for
+
+
+@pytest.mark.parametrize("make,width", [(scenes.small_mixed, 32), (scenes.cornell, 48), (scenes.extensions_demo, 40)])
+def test_accumulator_identical_however_the_shading_kernels_share_out_their_queues(make, width):
+    # PT_OPT_SHADE_CLAIM: pieces dealt out in advance (0), drawn in blocks of n chunks from a counter per XCD (n),
+    # or chosen step by step (-1, the default); both schedules, both estimators
+    from pathtracer_amd.core import PT_OPT_INTEGRATOR, PT_OPT_ROLLING, PT_OPT_SHADE_CLAIM
+    src = make(width, 36)
+    for integrator in (0, 1):
+        if integrator == 1 and make is scenes.extensions_demo:
+            continue  # next-event estimation refuses media and moving spheres
+        ref = None
+        for rolling, claim in ((1 << 22, 0), (1 << 22, -1), (1 << 22, 1), (1 << 22, 4), (3 * width * width, 2), (3 * width * width, 64), (0, 0), (0, 3)):
+            r = _renderer(src)
+            r.set_option(PT_OPT_INTEGRATOR, integrator)
+            r.set_option(PT_OPT_ROLLING, rolling)
+            r.set_option(PT_OPT_SHADE_CLAIM, claim)
+            r.render(0, 20, seed=5)
+            r.render(20, 36, seed=5)
+            acc, n = r.read_accum()
+            assert n == 36
+            if ref is None:
+                ref = acc
+            else:
+                assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"integrator={integrator} rolling={rolling} claim={claim}"
