@@ -38,10 +38,15 @@ pathtracer_amd/libptcore_check.so: $(CORE_SRC) $(CORE_DEP)
 	$(HIPCC) $(HIPFLAGS) -DPT_BOUNDS_CHECK -o $@ $(CORE_SRC) -ldl
 check-lib: pathtracer_amd/libptcore_check.so
 
+# The same library with the lane-occupancy counters of the walking kernel (PTCORE_LIB=... python tools/walk_stats.py knob 768).
+pathtracer_amd/libptcore_stats.so: $(CORE_SRC) $(CORE_DEP)
+	$(HIPCC) $(HIPFLAGS) -DPT_WALK_STATS -o $@ $(CORE_SRC) -ldl
+stats-lib: pathtracer_amd/libptcore_stats.so
+
 # Register / LDS / scratch use of every kernel (no output file).
 resources:
 	$(HIPCC) $(filter-out -shared -fPIC,$(HIPFLAGS)) --cuda-device-only -c -Rpass-analysis=kernel-resource-usage -o /dev/null pathtracer_amd/csrc/ptcore.hip 2>&1 | grep -E "Function Name|VGPRs:|SGPRs:|ScratchSize|Occupancy|LDS Size" | sed 's/.*remark: [^ ]* //' | paste - - - - - -
-.PHONY: resources check-lib
+.PHONY: resources check-lib stats-lib
 
 # Microbenchmarks behind design decisions (run on the GPU box).
 tools/micro/atomic_rate: tools/micro/atomic_rate.hip
