@@ -27,7 +27,30 @@ B_NODE, B_TRI, B_SPHERE, B_QUAD, B_RAY_IO = 32, 36, 16, 64, 32 + 16
 HBM_PEAK_GBS = 8000.0
 # wave64 vector instructions the chip can issue per second: 256 CUs x 4 SIMDs x 2.4 GHz, one every 2 cycles
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
-COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")  # tools/pmc_counters.py over this command
+
+
+def csrc_sha256() -> str:
+    """Identity of the kernel sources: counter files recorded for other sources are not used."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pathtracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def config_tag(args) -> str:
+    """Names the workload a counter file belongs to: profiles/r03_counters_<tag>.json (tools/pmc_counters.py)."""
+    tag = f"{args.scene}_{args.width}"
+    if args.extensions:
+        tag += "_ext"
+    if args.bsdf_probability != 1.0:
+        tag += f"_p{args.bsdf_probability:g}"
+    if args.integrator != "reference":
+        tag += f"_{args.integrator}"
+    return tag
 
 
 def cpu_baseline(src, budget_s: float = 12.0, bsdf_probability: float = 1.0):
@@ -56,8 +79,8 @@ def cpu_baseline(src, budget_s: float = 12.0, bsdf_probability: float = 1.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--strata-per-step", type=int, default=256)
     ap.add_argument("--scene", default="knob", choices=["knob", "cornell", "dragon_box", "interior", "next_week_like"])
@@ -184,25 +207,41 @@ def main():
         if world > 1:
             r.set_accum_from_device(accum_dev.data_ptr(), args.steps * S * world)
         img = r.read_rgb8()
-        # traversal work per ray on this rank's last step, counted by the device in the reference's order
+        # traversal work per ray on this rank's last step, counted by the device in the reference's order; once more with
+        # the camera's depth set to 1, which leaves the camera rays alone: the difference is the rays of later bounces
         r.stats_reset()
         if args.integrator == "nee":  # the counters exist for the reference's estimator only: its rays stand in
             r.set_option(PT_OPT_INTEGRATOR, 0)
         r.set_option(PT_OPT_COUNTERS, 1)
         r.reset_accum()
-        try:
-            step(args.warmup)
-            sc = r.stats()
-        except Exception as e:
-            print(f"no counted pass: {e}", file=sys.stderr)
-            sc = {"rays": 0, "node_tests": 0, "tri_tests": 0, "sphere_tests": 0, "quad_tests": 0}
+        zero = {"rays": 0, "node_tests": 0, "tri_tests": 0, "sphere_tests": 0, "quad_tests": 0}
+
+        def counted():
+            try:
+                r.stats_reset()
+                step(args.warmup)
+                return r.stats()
+            except Exception as e:
+                print(f"no counted pass: {e}", file=sys.stderr)
+                return dict(zero)
+
+        def bytes_per_ray(c):
+            return (B_NODE * c["node_tests"] + B_TRI * c["tri_tests"] + B_SPHERE * c["sphere_tests"] + B_QUAD * c["quad_tests"]) / max(1, c["rays"]) + B_RAY_IO
+
+        sc = counted()
+        import ctypes as C
+        cam_full = type(host.camera).from_buffer_copy(host.camera)
+        cam_one = type(host.camera).from_buffer_copy(host.camera)
+        cam_one.max_depth = 1
+        r._check(r.L.pt_set_camera(r.ctx, C.byref(cam_one)), "pt_set_camera")
+        sc_cam = counted() if sc["rays"] else dict(zero)
+        r._check(r.L.pt_set_camera(r.ctx, C.byref(cam_full)), "pt_set_camera")
         r.set_option(PT_OPT_COUNTERS, 0)
+        sc_bounce = {k: sc[k] - sc_cam[k] for k in zero}
         rays_c = max(1, sc["rays"])
-        b_ray = (B_NODE * sc["node_tests"] + B_TRI * sc["tri_tests"] + B_SPHERE * sc["sphere_tests"] + B_QUAD * sc["quad_tests"]) / rays_c + B_RAY_IO
-        # The closest-hit kernel on this rank over the timed region: averages over the launches that
-        # had rays, each bracketed by HIP events on its own stream.  Launches of different pipes overlap
-        # (each pipe has its own stream), so a launch shares the chip with the other pipe's kernels for
-        # part of its duration; the rate over the union of the launch intervals is reported beside it.
+        b_ray, b_ray_cam, b_ray_bounce = bytes_per_ray(sc), bytes_per_ray(sc_cam), bytes_per_ray(sc_bounce)
+        # The closest-hit search of a step on this rank over the timed region, bracketed by HIP events on its stream:
+        # averages over the launches that had rays.
         launches = max(1, st["extend_launches"])
         ext_ms_per_launch = st["extend_ms"] / launches
         rays_per_launch = st["rays"] / launches
@@ -210,16 +249,48 @@ def main():
         union_busy = st["rays"] * b_ray / busy_s / 1e9 if busy_s > 0 else 0.0
         launch_s = ext_ms_per_launch * 1e-3
         achieved = rays_per_launch * b_ray / launch_s / 1e9 if launch_s > 0 else 0.0
-        # counter-based figures: per-ray numbers of the committed rocprofv3 --pmc passes over this command,
-        # scaled by this run's rays per launch and divided by this run's launch duration
-        traffic = hbm_counter_frac = valu_issue_frac = lane_util = None
-        if args.scene == "knob" and args.width == 768 and os.path.exists(COUNTERS) and launch_s > 0:
-            with open(COUNTERS) as f:
+        # each of the two kernels with its own rays, its own bytes per ray and its own events (they run side by side,
+        # so each one's time is the time it took beside the other)
+        per_kernel = {}
+        if st["packet_launches"]:
+            kernels = (("k_extend_packet", st["paths"], st["packet_ms"], st["packet_launches"], b_ray_cam, "the paths that start with a step (camera rays), a wave at a time"),
+                       ("k_extend_walk", st["rays"] - st["paths"], st["walk_ms"], st["walk_launches"], b_ray_bounce, "the rays queued by earlier steps (later bounces), drawn by persistent waves"))
+        else:
+            kernels = (("k_extend_walk", st["rays"], st["walk_ms"], st["walk_launches"], b_ray, "all rays of a step, drawn by persistent waves (the camera rays have no kernel of their own in this configuration)"),)
+        for kname, krays, kms, kn, kb, what in kernels:
+            if kms > 0 and kn:
+                a = krays * kb / (kms * 1e-3) / 1e9
+                per_kernel[kname] = {"what": what, "rays": krays, "launches": kn, "ms_per_launch": kms / kn, "rays_per_launch": krays / kn, "Grays_per_s": krays / kms / 1e6,
+                                     "bytes_per_ray": kb, "achieved": a, "frac": a / HBM_PEAK_GBS, "saturated": a > HBM_PEAK_GBS}
+        # counter-based figures: per-ray numbers of rocprofv3 --pmc passes over this very command (tools/pmc_passes.sh,
+        # tools/pmc_counters.py), recorded in a file per configuration; used only when that file was taken with the
+        # kernel sources this library was built from
+        traffic = hbm_counter_frac = None
+        binding = None
+        counters_from = None
+        cfile = os.path.join(ROOT, "profiles", f"r03_counters_{config_tag(args)}.json")
+        if os.path.exists(cfile) and launch_s > 0:
+            with open(cfile) as f:
                 pc = json.load(f)
-            traffic = pc["hbm_bytes_per_ray"] * rays_per_launch
-            hbm_counter_frac = traffic / launch_s / (HBM_PEAK_GBS * 1e9)
-            valu_issue_frac = pc["valu_per_ray"] * rays_per_launch / launch_s / VALU_ISSUE_PEAK
-            lane_util = pc["lane_util"]
+            if pc.get("csrc_sha256") == csrc_sha256():
+                traffic = pc["hbm_bytes_per_ray"] * rays_per_launch
+                hbm_counter_frac = traffic / launch_s / (HBM_PEAK_GBS * 1e9)
+                valu_issue_frac = pc["valu_per_ray"] * rays_per_launch / launch_s / VALU_ISSUE_PEAK
+                binding = {"bound": "valu_issue", "frac": valu_issue_frac, "lane_util": pc["lane_util"], "useful_lane_frac": valu_issue_frac * pc["lane_util"],
+                           "peak": VALU_ISSUE_PEAK, "unit": "wave64 vector instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles)",
+                           "valu_per_ray": pc["valu_per_ray"], "salu_per_ray": pc["salu_per_ray"], "waves_parked": pc["wait_share_of_wave_cycles"]}
+                for kname in per_kernel:
+                    k = pc.get("per_kernel", {}).get(kname)
+                    if k:
+                        pk = per_kernel[kname]
+                        f_issue = k["valu_per_ray"] * pk["rays_per_launch"] / (pk["ms_per_launch"] * 1e-3) / VALU_ISSUE_PEAK
+                        pk["binding"] = {"bound": "valu_issue", "frac": f_issue, "lane_util": k["lane_util"], "useful_lane_frac": f_issue * k["lane_util"],
+                                         "valu_per_ray": k["valu_per_ray"], "salu_per_ray": k["salu_per_ray"]}
+                        pk["traffic"] = k["hbm_bytes_per_ray"] * pk["rays_per_launch"]
+                        pk["hbm_counter_frac"] = pk["traffic"] / (pk["ms_per_launch"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                counters_from = f"profiles/{os.path.basename(cfile)}: rocprofv3 --pmc passes of this command with these kernel sources (per-ray figures x this run's rays per launch / this run's launch time)"
+            else:
+                counters_from = f"profiles/{os.path.basename(cfile)} was recorded with other kernel sources: not used"
         out = {
             "metric": "Mrays/s & spp/s, mitsuba knob 768^2 Disney" if args.scene == "knob" else f"Mrays/s & spp/s, {args.scene}",
             "value": rays_all / dt / 1e6,
@@ -227,6 +298,7 @@ def main():
             "spp_per_s": args.steps * S * world / dt,
             "paths_per_s": paths_all / dt,
             "rays": rays_all,
+            "paths": paths_all,
             "mean_path_length": rays_all / max(1.0, paths_all),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -241,16 +313,19 @@ def main():
                        "schedule": (f"rolling, up to {args.rolling} paths started per launch" if args.rolling > 0 else
                                     "library default (rolling, one pipe, up to 32 M paths started per launch)" if args.rolling < 0 else "one batch at a time per pipe")},
             "roofline": {"bound": "hbm", "kernel": "k_extend_walk + k_extend_packet (one step's closest-hit search: queued rays and new paths, side by side)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "hbm_counter_frac": hbm_counter_frac, "valu_issue_frac": valu_issue_frac, "lane_util": lane_util,
-                         "counters_from": "profiles/r02_counters.json: rocprofv3 --pmc passes of this command, recorded (per-ray figures scaled by this run's rays and launch time)" if traffic is not None else None,
-                         "bytes_per_ray": b_ray, "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
+                         "frac": achieved / HBM_PEAK_GBS, "saturated": achieved > HBM_PEAK_GBS,
+                         "note": "algorithmic bytes (what a ray would read with no cache) over measured launch time; above 1 the tree is served by the caches and this yardstick is saturated: `binding` says what bounds the kernel",
+                         "traffic": traffic, "hbm_counter_frac": hbm_counter_frac, "binding": binding, "counters_from": counters_from,
+                         "per_kernel": per_kernel,
+                         "bytes_per_ray": b_ray, "bytes_per_camera_ray": b_ray_cam, "bytes_per_bounce_ray": b_ray_bounce,
+                         "rays_per_launch": rays_per_launch, "ms_per_launch": ext_ms_per_launch,
                          "launches": st["extend_launches"], "busy_ms": st["extend_busy_ms"],
                          "achieved_over_union_of_launches": union_busy,
                          "launches_in_flight": st["extend_ms"] / st["extend_busy_ms"] if st["extend_busy_ms"] > 0 else 0.0,
                          "node_tests_per_ray": sc["node_tests"] / rays_c, "tri_tests_per_ray": sc["tri_tests"] / rays_c},
             "kernel_ms": {"extend": st["extend_ms"], "shade": st["shade_ms"], "other": st["other_ms"]},
             "device_bytes": st["device_bytes"],
+            "csrc_sha256": csrc_sha256(),
             "host_wait_ms": st["host_wait_ms"],
             "image_mean": float(img.mean()),
         }

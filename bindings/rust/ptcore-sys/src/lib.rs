@@ -220,6 +220,10 @@ pub struct pt_stats {
     pub quad_tests: u64,
     pub device_bytes: u64,
     pub bad_refs: u64,
+    pub walk_ms: f64,
+    pub packet_ms: f64,
+    pub walk_launches: u64,
+    pub packet_launches: u64,
 }
 
 #[repr(C)]

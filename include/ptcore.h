@@ -160,6 +160,12 @@ typedef struct pt_stats {
     uint64_t node_tests, tri_tests, sphere_tests, quad_tests;
     uint64_t device_bytes;    /* device memory held by the context */
     uint64_t bad_refs;        /* out-of-range scene references caught by a library built with PT_BOUNDS_CHECK (else 0) */
+    /* the two closest-hit kernels of a step, each bracketed by its own events (only with PT_OPT_PROFILE; they run
+       side by side on two streams, so the two do not add up to extend_ms): */
+    double walk_ms;           /* the ray-drawing kernel: the rays queued by earlier steps (all rays where camera rays
+                                 have no kernel of their own) */
+    double packet_ms;         /* the camera-ray kernel: the paths that start with the step, a wave at a time */
+    uint64_t walk_launches, packet_launches; /* launches those times are summed over */
 } pt_stats;
 
 enum {
@@ -257,13 +263,16 @@ int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *o
 int pt_trace_first_hit_at(pt_context *ctx, const float *rays, const float *times, uint64_t n, pt_hit *out);
 
 /* No counterpart in the reference.  pt_trace_first_hit for callers that cannot allocate device memory
- * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels,
- * with everything they need beyond the rays and the hits (path state, the ray queue, the spilled part of
- * the traversal stacks) in a fixed array that the library holds on every GPU it runs on (about 45 MB per
- * GPU, until the process ends).  The call allocates and frees nothing.  rays_device[n][8] and
- * out_device[n] are DEVICE memory of ctx's GPU; the call returns when out_device is complete.  At most
- * PT_STATIC_TRACE_MAX_RAYS rays per call (PT_ERR_INVALID beyond that).  All contexts of one GPU share the
- * array: two such calls that overlap in time on one GPU race; serialise them. */
+ * (tight serving loops, harnesses that forbid hipMalloc, code that runs between the captures of a HIP graph):
+ * the same kernels, with everything they need beyond the rays and the hits (path state, the ray queue, the
+ * spilled part of the traversal stacks) in a fixed array that the library holds on every GPU it runs on (about
+ * 45 MB per GPU, until the process ends).  The call allocates and frees nothing.  rays_device[n][8] and
+ * out_device[n] are DEVICE memory of ctx's GPU.  The call runs on the context's own stream and waits for it, so
+ * it cannot itself be captured into a graph, and it is not ordered against work the caller has queued on other
+ * streams: rays_device must be complete before the call, and out_device is complete when it returns.  At most
+ * PT_STATIC_TRACE_MAX_RAYS rays per call (PT_ERR_INVALID beyond that).  All contexts of one GPU share the array;
+ * the library lets one such call at a time run per GPU (a host mutex), so concurrent callers on different
+ * threads are safe and take turns. */
 #define PT_STATIC_TRACE_MAX_RAYS 262144u
 int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_t n, pt_hit *out_device);
 
@@ -326,8 +335,10 @@ int pt_stats_reset(pt_context *ctx);
  * device with one RCCL ncclReduce (sum, f32, W*H*3 values) and add up the pass counts (src/camera.rs:199); f32
  * sums are re-associated, so a group's image equals one context's to rounding, not bits.  Rendering may go on
  * after a read: the members' own accumulators are left as they are.  A group that lists a device more than once
- * is summed with copies instead of RCCL (for rehearsing the split on one GPU).  librccl.so is opened when a
- * group is created, not when libptcore is loaded.  One group is not re-entrant. */
+ * is summed with copies instead of RCCL (for rehearsing the split on one GPU), and a group of one device needs no
+ * collective at all.  librccl.so is opened when a group of several distinct devices is created, not when libptcore
+ * is loaded, and on a thread of its own: opening it and making the communicators takes seconds, which the first
+ * read waits for and uploads and rendering do not (a failure is reported by that read).  One group is not re-entrant. */
 typedef struct pt_group pt_group;
 int pt_group_create(const int *devices, int n, pt_group **out);
 void pt_group_destroy(pt_group *g);

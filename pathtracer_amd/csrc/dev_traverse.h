@@ -270,6 +270,56 @@ __device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint3
     hit_quad(sc.quads[4 * g], sc.quads[4 * g + 1], sc.quads[4 * g + 2], sc.quads[4 * g + 3], g, r, h, inst_code);
 }
 
+// One lane's search of a buffer whose tree was built on the device (64-byte two-box nodes only): the order of
+// tests the ray-drawing search (dev_walk.h) makes for it: both boxes at the parent, the near child first, the far
+// one stacked with its entry distance and dropped when popped if t_max has shrunk below it.
+template <class LeafFn>
+__device__ __noinline__ void traverse_wide(const DevScene &sc, const DevBuffer &buf, TravRay &r, LaneStack &st, TravCounters &tc, LeafFn &&leaf) {
+        float e;
+        tc.nodes++;
+        if (!slab_test_entry(buf.rmin[0], buf.rmin[1], buf.rmin[2], buf.rmax[0], buf.rmax[1], buf.rmax[2], r, e)) return;
+        const int floor = st.enter();
+        const float4 *wide = sc.wide + 4 * (size_t)buf.wide_first;
+        uint32_t cur = buf.root_ref;
+        for (;;) {
+            bool pop = true;
+            if (cur & WIDE_LEAF) {  // WIDE_LEAF | count << 24 | offset
+                const uint32_t first = buf.prim_first + (cur & 0xFFFFFFu), cnt = (cur >> 24) & 0x7Fu;
+#pragma unroll 1
+                for (uint32_t i = 0; i < cnt; i++) leaf(first + i);
+            } else {
+                const float4 a = wide[4 * (size_t)cur], b = wide[4 * (size_t)cur + 1], c = wide[4 * (size_t)cur + 2], d = wide[4 * (size_t)cur + 3];
+                float el, er;
+                tc.nodes += 2;
+                const bool hl = slab_test_entry(a.x, a.y, a.z, a.w, b.x, b.y, r, el);
+                const bool hr = slab_test_entry(b.z, b.w, c.x, c.y, c.z, c.w, r, er);
+                const uint32_t lref = __float_as_uint(d.x), rref = __float_as_uint(d.y), axis = __float_as_uint(d.z);
+                const float da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
+                const bool neg = da < 0.0f;
+                const uint32_t near_ref = neg ? rref : lref, far_ref = neg ? lref : rref;
+                const bool hn = neg ? hr : hl, hf = neg ? hl : hr;
+                if (hn) {
+                    if (hf) st.push(far_ref, neg ? el : er);
+                    cur = near_ref;
+                    pop = false;
+                } else if (hf) {
+                    cur = far_ref;
+                    pop = false;
+                }
+            }
+            if (pop) {
+                bool got = false;
+                while (st.pop(floor, cur, e)) {
+                    if (!(r.t_max < e)) {
+                        got = true;
+                        break;
+                    }
+                }
+                if (!got) break;
+            }
+        }
+}
+
 // ---------------------------------------------------------------------------------------
 // The reference's loop verbatim over 32-byte nodes (InnerPrimitiveBuffer::traverse,
 // src/bvh.rs:725-797): one AABB per visit, near child first by the sign of the direction on
@@ -280,6 +330,10 @@ template <class LeafFn>
 __device__ __forceinline__ void traverse(const DevScene &sc, const DevBuffer &buf, TravRay &r, LaneStack &st, TravCounters &tc,
                                          LeafFn &&leaf) {
     if (buf.prim_count == 0) return;
+    if (buf.tree == 2u) {
+        traverse_wide(sc, buf, r, st, tc, leaf);
+        return;
+    }
     if (buf.node_count == 0) {  // no BVH: src/bvh.rs:726-737
 #pragma unroll 1
         for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i);

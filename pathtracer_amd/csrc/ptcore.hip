@@ -152,14 +152,17 @@ struct pt_context {
         std::vector<uint32_t> drain_rays;
         std::deque<Due> due;
         hipEvent_t done[ROLL_RING] = {}, accumulated[ROLL_RING] = {};
-        hipEvent_t prof[ROLL_RING][4] = {};  // before raygen, before extend, after extend, after shading
-        bool prof_pending[ROLL_RING] = {};
+        // before raygen, before extend, after extend, after shading; around the camera-ray kernel on its side stream (4, 5);
+        // after the ray-drawing kernel, before it waits for the other (6)
+        hipEvent_t prof[ROLL_RING][7] = {};
+        bool prof_pending[ROLL_RING] = {}, prof_packet[ROLL_RING] = {}, prof_walk[ROLL_RING] = {};
     };
     static constexpr int MAX_PIPES = 8;
     Pipe pipes[MAX_PIPES];
     Roll rolls[MAX_PIPES];
     uint64_t roll_seq = 0;        // ticks over all pipes so far (picks the pipe: strictly round-robin)
     int64_t roll_k = -1;             // strata per tick decided for the current scene, camera and options (-1: not yet)
+    uint32_t roll_seen = 0;          // ... of which so many are used: the largest number one pt_render call has asked for so far
     uint64_t untraced_paths = 0;  // camera paths of renders with max_depth 0, which start and end on the host
     uint64_t roll_paths = 32000000;  // paths started per tick; 0 = one batch at a time per pipe
     int n_pipes = 4;       // batch-at-a-time schedule
@@ -179,7 +182,8 @@ struct pt_context {
     std::vector<double> bounce_extend_ms, bounce_shade_ms;  // per bounce, summed over batches (profiling)
     uint64_t profiled_batches = 0;
     double host_wait_ms = 0;  // part of render_ms spent waiting so as not to run too far ahead of the device
-    double extend_ms = 0, shade_ms = 0, other_ms = 0, render_ms = 0;
+    double extend_ms = 0, shade_ms = 0, other_ms = 0, render_ms = 0, walk_ms = 0, packet_ms = 0;
+    uint64_t walk_launches = 0, packet_launches = 0;
     uint64_t device_bytes = 0;
 };
 
@@ -287,6 +291,30 @@ static int grid_fixed(const pt_context *ctx, uint64_t upper_bound, int blocks_pe
 }
 
 static hipError_t scratch_lookup(int device);
+
+// Streams, events and pinned words of pipe i, made when the pipe is first used: the defaults use one pipe, and a
+// context that made all eight at creation spent most of its set-up time on them.
+static hipError_t pipe_init(pt_context *ctx, int i) {
+    pt_context::Pipe &pp = ctx->pipes[i];
+    pt_context::Roll &r = ctx->rolls[i];
+    if (pp.fork) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (!pp.stream) e = hipStreamCreate(&pp.stream);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&pp.fork, hipEventDisableTiming);
+    for (int k = 0; k < pt_context::Pipe::N_SIDE && e == hipSuccess; k++) {
+        e = hipStreamCreateWithFlags(&pp.side[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pp.join[k], hipEventDisableTiming);
+    }
+    for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&pp.accumulated[k], hipEventDisableTiming);
+    for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc((void **)&pp.host_chunks[k], BOUNCE_PROFILE_LEN * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&r.host_tick_rays, pt_context::ROLL_RING * sizeof(uint32_t), hipHostMallocDefault);
+    for (int k = 0; k < pt_context::ROLL_RING && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&r.accumulated[k], hipEventDisableTiming);
+        for (int j = 0; j < 7 && e == hipSuccess; j++) e = hipEventCreate(&r.prof[k][j]);
+    }
+    return e;
+}
 
 static void free_roll(pt_context *ctx, pt_context::Roll &r) {
     free_pool(ctx, r.allocs);
@@ -449,38 +477,37 @@ int pt_create(int device, pt_context **out) {
     pt_context *ctx = new (std::nothrow) pt_context();
     if (!ctx) return fail(nullptr, PT_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    // PT_DEBUG_CREATE: where the time of this call goes, to stderr
+    const bool timing = getenv("PT_DEBUG_CREATE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "pt_create: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     if ((e = hipSetDevice(device)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PT_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     }
+    lap("hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) == hipSuccess) ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    lap("hipGetDeviceProperties");
     if ((e = scratch_lookup(device)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PT_ERR_HIP, "hipGetSymbolAddress of the static scratch array on device %d: %s", device, hipGetErrorString(e));
     }
+    lap("static array address");
     if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
         delete ctx;
         return fail(nullptr, PT_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    lap("hipStreamCreate");
     ctx->pipes[0].stream = ctx->stream;
     e = hipEventCreate(&ctx->epoch);
-    for (int i = 0; i < pt_context::MAX_PIPES && e == hipSuccess; i++) {
-        if (i > 0) e = hipStreamCreate(&ctx->pipes[i].stream);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].fork, hipEventDisableTiming);
-        for (int k = 0; k < pt_context::Pipe::N_SIDE && e == hipSuccess; k++) {
-            e = hipStreamCreateWithFlags(&ctx->pipes[i].side[k], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->pipes[i].join[k], hipEventDisableTiming);
-        }
-        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ctx->pipes[i].accumulated[k], hipEventDisableTiming);
-        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc((void **)&ctx->pipes[i].host_chunks[k], BOUNCE_PROFILE_LEN * sizeof(uint32_t), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&ctx->rolls[i].host_tick_rays, pt_context::ROLL_RING * sizeof(uint32_t), hipHostMallocDefault);
-        for (int k = 0; k < pt_context::ROLL_RING && e == hipSuccess; k++) {
-            e = hipEventCreateWithFlags(&ctx->rolls[i].done[k], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->rolls[i].accumulated[k], hipEventDisableTiming);
-            for (int j = 0; j < 4 && e == hipSuccess; j++) e = hipEventCreate(&ctx->rolls[i].prof[k][j]);
-        }
-    }
+    if (e == hipSuccess) e = pipe_init(ctx, 0);  // the other pipes get their streams and events when first used
+    lap("streams, events, pinned words");
     void *p = nullptr;
     if (e != hipSuccess || (e = hipMalloc(&p, sizeof(DevStats))) != hipSuccess) {
         destroy_pipes(ctx);
@@ -489,6 +516,7 @@ int pt_create(int device, pt_context **out) {
     }
     ctx->stats = (DevStats *)p;
     (void)hipMemset(ctx->stats, 0, sizeof(DevStats));
+    lap("counters");
     *out = ctx;
     return PT_OK;
 }
@@ -1116,11 +1144,14 @@ int pt_set_camera(pt_context *ctx, const pt_camera_desc *c) {
 // ---------------------------------------------------------------- path state
 // Queue capacities in chunks for path state of n_slots paths.  A closed chunk holds more than QUEUE_CHUNK - 64
 // entries, and every producing wave of every launch that fills a queue may leave one open chunk behind: a
-// material queue is filled by one closest-hit launch, a ray queue (and the shadow-ray queue) by one shading
-// launch per material type in use.
+// material queue is filled by the closest-hit launches of a step (two side by side when the camera rays have
+// their own kernel), a ray queue (and the shadow-ray queue) by one shading launch per material type in use.
 static void queue_capacity(const pt_context *ctx, uint64_t n_slots, uint64_t &max_chunks, uint64_t &max_ray_chunks) {
     const uint64_t max_waves = (uint64_t)ctx->n_cu * std::max({ctx->blocks_per_cu, ctx->shade_blocks_per_cu, 8}) * (BLOCK / 64);
-    max_chunks = n_slots / (QUEUE_CHUNK - 63u) + max_waves + 8u;
+    // the material queues of a step are filled by the ray-drawing kernel and, beside it, by the camera-ray kernel
+    // (8 workgroups per CU): each wave of either may leave one open chunk per queue
+    const uint64_t packet_waves = (uint64_t)ctx->n_cu * 8u * (BLOCK / 64);
+    max_chunks = n_slots / (QUEUE_CHUNK - 63u) + max_waves + packet_waves + 8u;
     max_ray_chunks = n_slots / (QUEUE_CHUNK - 63u) + (uint64_t)std::max<uint32_t>(1u, ctx->n_queues) * max_waves + 8u;
 }
 
@@ -1207,8 +1238,11 @@ static hipEvent_t get_event(pt_context::Pipe &pp, size_t i) {
 // fp: the paths that start with this step (on their camera rays; nothing is stored for them).
 // side, fork, join: a second stream of the pipe with two events (or null): where k_extend_packet runs.
 // queued: about how many rays the ray queue holds (the last count the host has seen).
+// prof (or null): three events: around the camera-ray kernel on its stream, and after the ray-drawing kernel; *packet_used: whether
+// the camera-ray kernel was launched.
 static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathState &ps, uint32_t bounce, FreshPaths fp, hipStream_t side = nullptr,
-                          hipEvent_t fork = nullptr, hipEvent_t join = nullptr, uint64_t queued = 0) {
+                          hipEvent_t fork = nullptr, hipEvent_t join = nullptr, uint64_t queued = 0, hipEvent_t *prof = nullptr, bool *packet_used = nullptr) {
+    if (packet_used) *packet_used = false;
     dim3 g(grid);
     const dim3 b(BLOCK);
     const f3 bg = ctx->cam.background;
@@ -1232,12 +1266,15 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
             const unsigned per_cu = 8u;
             const dim3 gp((unsigned)std::min<uint64_t>(((uint64_t)fp.n_new + BLOCK - 1) / BLOCK, (uint64_t)ctx->n_cu * per_cu));
 #define EXP(I, M) hipLaunchKernelGGL((k_extend_packet<I, M>), gp, b, 0, side, ctx->scene, ctx->cam, ps, bounce, bg, fp, ctx->stats)
+            if (prof) (void)hipEventRecord(prof[0], side);
             if (ctx->scene.n_moving != 0) {
                 if (insts) EXP(true, true); else EXP(false, true);
             } else {
                 if (insts) EXP(true, false); else EXP(false, false);
             }
 #undef EXP
+            if (prof) (void)hipEventRecord(prof[1], side);
+            if (packet_used) *packet_used = true;
             (void)hipEventRecord(join, side);
             walk_fp.n_new = 0u;
             const int beside = mostly_new ? 4 : 5;
@@ -1252,6 +1289,7 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
         }
 #undef EXWF
 #undef EXW
+        if (prof) (void)hipEventRecord(prof[2], st);
         if (walk_fp.n_new != fp.n_new) (void)hipStreamWaitEvent(st, join, 0);
     } else {
         if (insts) { EXT(false, false); EXI(false); } else EXT(false, true);
@@ -1478,6 +1516,16 @@ static void harvest_roll(pt_context *ctx, pt_context::Roll &r, int ring) {
         if (hipEventElapsedTime(&since, ctx->epoch, r.prof[ring][1]) == hipSuccess) ctx->extend_iv.push_back({since, since + ms});
     }
     if (hipEventElapsedTime(&ms, r.prof[ring][2], r.prof[ring][3]) == hipSuccess) ctx->shade_ms += ms;
+    if (r.prof_walk[ring]) {
+        if (hipEventElapsedTime(&ms, r.prof[ring][1], r.prof[ring][6]) == hipSuccess) {
+            ctx->walk_ms += ms;
+            ctx->walk_launches++;
+        }
+        if (r.prof_packet[ring] && hipEventElapsedTime(&ms, r.prof[ring][4], r.prof[ring][5]) == hipSuccess) {
+            ctx->packet_ms += ms;
+            ctx->packet_launches++;
+        }
+    }
     ctx->profiled_batches++;
 }
 
@@ -1522,6 +1570,7 @@ static uint32_t roll_learn(pt_context *ctx) {
 // flight might not fit the pipe's arrays, and the tick then only advances what is under way.
 static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nullptr) {
     const int p = (int)(ctx->roll_seq % (uint64_t)ctx->n_roll_pipes);
+    HIP_TRY(ctx, pipe_init(ctx, p));
     pt_context::Pipe &pp = ctx->pipes[p];
     pt_context::Roll &r = ctx->rolls[p];
     const int ring = (int)(r.tick % pt_context::ROLL_RING);
@@ -1582,7 +1631,9 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
     hipLaunchKernelGGL(k_tick_begin, dim3(1), dim3(1), 0, st, ps.regions, region, rp, nb ? 1u : 0u, ps.next_rays);
     if (prof) (void)hipEventRecord(r.prof[ring][1], st);
     const uint64_t bound = r.n_live + r.cap;
-    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp, pp.side[0], pp.fork, pp.join[0], r.known_rays);
+    r.prof_walk[ring] = prof && ctx->use_wide() && !ctx->counters;
+    launch_extend(ctx, st, grid_fixed(ctx, bound), ps, parity, fp, pp.side[0], pp.fork, pp.join[0], r.known_rays, r.prof_walk[ring] ? &r.prof[ring][4] : nullptr,
+                  &r.prof_packet[ring]);
     if (prof) (void)hipEventRecord(r.prof[ring][2], st);
     BatchParams common{};
     common.npix = ctx->cam.width * ctx->cam.height;
@@ -1629,7 +1680,10 @@ static uint32_t roll_strata_now(pt_context *ctx);
 static uint32_t roll_strata(pt_context *ctx) {
     // decided once per scene / camera / option change: the answer depends on the free memory at that time, and
     // a different one later would mean reallocating the path state in the middle of a render
-    if (ctx->roll_k < 0) ctx->roll_k = (int64_t)roll_strata_now(ctx);
+    if (ctx->roll_k < 0) {
+        ctx->roll_k = (int64_t)roll_strata_now(ctx);
+        ctx->roll_seen = 0;
+    }
     return (uint32_t)ctx->roll_k;
 }
 static uint32_t roll_strata_now(pt_context *ctx) {
@@ -1682,7 +1736,11 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         ctx->untraced_paths += (uint64_t)total * npix;
         return PT_OK;
     }
-    if (const uint32_t k_tick = roll_strata(ctx)) {
+    if (uint32_t k_tick = roll_strata(ctx)) {
+        // the path state is sized by the work asked for: a caller that renders a few strata at a time gets launches
+        // (and slot arrays) of that size, not of the largest size a launch may have; a larger request later grows them
+        ctx->roll_seen = std::max(ctx->roll_seen, std::min(total, k_tick));
+        k_tick = std::min(k_tick, ctx->roll_seen);
         const uint32_t depth = ctx->cam.max_depth, cap_slots = npix * k_tick;
         const uint64_t n_live = roll_live(ctx, depth, cap_slots);
         bool fits = true;
@@ -1690,8 +1748,10 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
         for (int p = 0; p < ctx->n_roll_pipes; p++) fits = fits && ctx->rolls[p].n_regions == regions && ctx->rolls[p].cap == cap_slots && ctx->rolls[p].n_live == n_live;
         if (!fits) {
             sync_pipes(ctx);
-            for (int p = 0; p < ctx->n_roll_pipes; p++)
+            for (int p = 0; p < ctx->n_roll_pipes; p++) {
+                HIP_TRY(ctx, pipe_init(ctx, p));
                 if ((rc = ensure_roll(ctx, ctx->pipes[p], ctx->rolls[p], regions, cap_slots, n_live))) return rc;
+            }
         }
         const uint32_t n_batches = (total + k_tick - 1) / k_tick, per_batch = (total + n_batches - 1) / n_batches;
         for (uint32_t s = stratum_begin; s < stratum_end;) {
@@ -1713,6 +1773,7 @@ int pt_render(pt_context *ctx, uint32_t stratum_begin, uint32_t stratum_end, uin
     // k_accumulate of batch i runs on batch i's stream after batch i-1's k_accumulate, so each
     // pixel receives its samples in stratum order whatever the overlap (camera.rs:212-217).
     for (uint32_t s = stratum_begin; s < stratum_end;) {
+        HIP_TRY(ctx, pipe_init(ctx, (int)(ctx->batch_seq % (uint64_t)ctx->n_pipes)));
         pt_context::Pipe &pp = ctx->pipes[ctx->batch_seq % (uint64_t)ctx->n_pipes];
         const uint32_t k = std::min(per_batch, stratum_end - s);
         // the host runs at most two batches ahead of each pipe
@@ -1839,6 +1900,7 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
         hipLaunchKernelGGL(k_load_rays, dim3(grid_for(ctx, n)), dim3(BLOCK), 0, st, d_rays, pp.ps, (uint32_t)n);
         const dim3 g(grid_fixed(ctx, n)), b(BLOCK);
         const bool insts = ctx->scene.world.insts.prim_count != 0;
+        if (ctx->profile) (void)hipEventRecord(ctx->rolls[0].prof[0][0], st);  // the search itself, for pt_stats::extend_ms
         if (ctx->trace_packet && ctx->packet_ok) {
             if (insts) hipLaunchKernelGGL((k_trace_packet<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
             else hipLaunchKernelGGL((k_trace_packet<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
@@ -1850,12 +1912,17 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
             if (insts) hipLaunchKernelGGL(k_trace_inst, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         }
         if (with_moving) hipLaunchKernelGGL(k_trace_moving, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, pp.ps, (uint32_t)n, d_times);
+        if (ctx->profile) (void)hipEventRecord(ctx->rolls[0].prof[0][1], st);
         hipLaunchKernelGGL(k_trace_out, dim3(grid_for(ctx, n)), b, 0, st, ctx->scene, pp.ps, (uint32_t)n, d_out);
         e = hipMemcpyAsync(out, d_out, n * sizeof(pt_hit), hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(ctx, PT_ERR_HIP, "pt_trace_first_hit: %s", hipGetErrorString(e));
+    if (ctx->profile) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ctx->rolls[0].prof[0][0], ctx->rolls[0].prof[0][1]) == hipSuccess) ctx->extend_ms += ms;
+    }
     return sync_all(ctx);
 }
 int pt_trace_first_hit(pt_context *ctx, const float *rays, uint64_t n, pt_hit *out) { return trace_first_hit(ctx, rays, nullptr, false, n, out); }
@@ -1887,6 +1954,7 @@ static __device__ __align__(256) unsigned char scratch[STATIC_BYTES];
 
 constexpr int STATIC_MAX_DEVICES = 64;
 static unsigned char *g_scratch_ptr[STATIC_MAX_DEVICES];  // device address of `scratch` on each GPU seen so far
+static std::mutex g_scratch_mutex[STATIC_MAX_DEVICES];    // held for the length of a call that uses it
 
 // Called by pt_create with `device` current.
 static hipError_t scratch_lookup(int device) {
@@ -1930,6 +1998,8 @@ int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_
     ps.shade_claim = 0u;
     ps.shade_claim_from = 0u;
     hipStream_t st = ctx->stream;
+    // every context of this GPU uses the same array: one call at a time per device (a mutex allocates nothing)
+    std::lock_guard<std::mutex> one_at_a_time(g_scratch_mutex[ctx->device]);
     // the array keeps what the last call on this GPU left in it: the control words start from zero
     HIP_TRY(ctx, hipMemsetAsync(ps.ctl, 0, (size_t)CTL_WORDS * sizeof(uint32_t), st));
     const uint64_t want = (n + BLOCK - 1) / BLOCK;
@@ -2095,6 +2165,10 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
     out->sphere_tests = ds.sphere_tests;
     out->quad_tests = ds.quad_tests;
     out->bad_refs = ds.bad_refs[0] + ds.bad_refs[1];
+    out->walk_ms = ctx->walk_ms;
+    out->packet_ms = ctx->packet_ms;
+    out->walk_launches = ctx->walk_launches;
+    out->packet_launches = ctx->packet_launches;
     out->device_bytes = ctx->device_bytes;
     if (getenv("PT_DEBUG_BOUNCES") && ctx->profiled_batches) {  // per-bounce means of the event timings, for tuning
         fprintf(stderr, "bounce: extend ms, shade ms (mean of %llu batches), rays in the last profile\n", (unsigned long long)ctx->profiled_batches);
@@ -2113,7 +2187,8 @@ int pt_stats_reset(pt_context *ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (int rc = restart_epoch(ctx)) return rc;
     HIP_TRY(ctx, hipMemset(ctx->stats, 0, sizeof(DevStats)));
-    ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = ctx->host_wait_ms = 0.0;
+    ctx->extend_ms = ctx->extend_busy_ms = ctx->shade_ms = ctx->other_ms = ctx->render_ms = ctx->host_wait_ms = ctx->walk_ms = ctx->packet_ms = 0.0;
+    ctx->walk_launches = ctx->packet_launches = 0;
     ctx->untraced_paths = 0;
     ctx->bounce_extend_ms.clear();
     ctx->bounce_shade_ms.clear();

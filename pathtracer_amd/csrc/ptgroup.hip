@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -70,12 +71,22 @@ __global__ void k_add_into(float *dst, const float *src, size_t n) {
 struct pt_group {
     std::vector<pt_context *> members;
     std::vector<int> devices;
-    bool distinct = true;  // no device listed twice: the merge is an RCCL reduce
+    bool distinct = true;  // no device listed twice
+    // The merge is an RCCL reduce when the group has several distinct devices.  Opening librccl and making the
+    // communicators takes seconds, so it runs on a thread of its own from pt_group_create on and is waited for by the
+    // first merge: scene upload and rendering do not wait for it.  A group of one device needs no collective (its
+    // merge is a copy), unless PT_GROUP_RCCL_ALWAYS is set in the environment, which keeps the one-rank reduce
+    // available for testing the call path on a machine with a single GPU.
+    bool use_rccl = false;
+    std::thread rccl_thread;
+    int rccl_rc = PT_OK;
+    std::string rccl_err;
     Rccl rccl;
     std::vector<ncclComm_t> comms;
     float *reduced = nullptr;  // on the first member's device: the sum of all accumulators, W*H*3 f32
     float *staging = nullptr;  // likewise, for the merge without RCCL
     uint64_t film_pixels = 0;  // pixels `reduced` / `staging` are allocated for
+    bool film_pixels_valid = false;  // every member has the camera those buffers belong to
     std::string err;
 };
 
@@ -110,8 +121,15 @@ void pt_group_split(uint32_t stratum_begin, uint32_t stratum_end, int n, int i, 
     if (end_i) *end_i = b + q + (k < r ? 1u : 0u);
 }
 
+// Waits for the RCCL set-up started by pt_group_create; its result.
+static int rccl_wait(pt_group *g) {
+    if (g->rccl_thread.joinable()) g->rccl_thread.join();
+    return g->rccl_rc;
+}
+
 void pt_group_destroy(pt_group *g) {
     if (!g) return;
+    (void)rccl_wait(g);
     for (size_t i = 0; i < g->comms.size(); i++)
         if (g->comms[i]) (void)g->rccl.CommDestroy(g->comms[i]);
     if (!g->members.empty()) {
@@ -132,31 +150,47 @@ int pt_group_create(const int *devices, int n, pt_group **out) {
     if (!g) return gfail(nullptr, PT_ERR_NOMEM, "out of host memory");
     g->devices.assign(devices, devices + n);
     g->distinct = std::set<int>(g->devices.begin(), g->devices.end()).size() == (size_t)n;
-    for (int i = 0; i < n; i++) {
-        pt_context *c = nullptr;
-        const int rc = pt_create(devices[i], &c);
-        if (rc) {
-            gfail(nullptr, rc, "member %d (device %d): %s", i, devices[i], pt_last_error(nullptr));
+    // one host thread per member: creating a context (streams, events, pinned words) takes a while, and the
+    // members do not depend on each other
+    g->members.assign((size_t)n, nullptr);
+    std::vector<int> rcs((size_t)n, PT_OK);
+    std::vector<std::string> errs((size_t)n);
+    auto make = [&](int i) {
+        rcs[(size_t)i] = pt_create(devices[i], &g->members[(size_t)i]);
+        if (rcs[(size_t)i]) errs[(size_t)i] = pt_last_error(nullptr);  // thread-local: read on the thread that failed
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n; i++) pool.emplace_back(make, i);
+        make(0);
+        for (auto &t : pool) t.join();
+    }
+    for (int i = 0; i < n; i++)
+        if (rcs[(size_t)i]) {
+            const int rc = rcs[(size_t)i];
+            gfail(nullptr, rc, "member %d (device %d): %s", i, devices[i], errs[(size_t)i].c_str());
+            g->members.erase(std::remove(g->members.begin(), g->members.end(), nullptr), g->members.end());
             pt_group_destroy(g);
             return rc;
         }
-        g->members.push_back(c);
-    }
-    if (g->distinct) {
-        std::string why;
-        if (!g->rccl.open(why)) {
-            gfail(nullptr, PT_ERR_UNSUPPORTED, "pt_group_create: %s", why.c_str());
-            pt_group_destroy(g);
-            return PT_ERR_UNSUPPORTED;
-        }
+    g->use_rccl = g->distinct && (n > 1 || getenv("PT_GROUP_RCCL_ALWAYS") != nullptr);
+    if (g->use_rccl) {
         g->comms.assign((size_t)n, nullptr);
-        const ncclResult_t e = g->rccl.CommInitAll(g->comms.data(), n, g->devices.data());
-        if (e != ncclSuccess) {
-            gfail(nullptr, PT_ERR_HIP, "ncclCommInitAll over %d devices: %s", n, g->rccl.GetErrorString(e));
-            g->comms.clear();
-            pt_group_destroy(g);
-            return PT_ERR_HIP;
-        }
+        g->rccl_thread = std::thread([g, n] {
+            std::string why;
+            if (!g->rccl.open(why)) {
+                g->rccl_err = "pt_group_create: " + why;
+                g->rccl_rc = PT_ERR_UNSUPPORTED;
+                g->comms.clear();
+                return;
+            }
+            const ncclResult_t e = g->rccl.CommInitAll(g->comms.data(), n, g->devices.data());
+            if (e != ncclSuccess) {
+                g->rccl_err = std::string("ncclCommInitAll: ") + g->rccl.GetErrorString(e);
+                g->rccl_rc = PT_ERR_HIP;
+                g->comms.clear();
+            }
+        });
     }
     *out = g;
     return PT_OK;
@@ -166,30 +200,41 @@ const char *pt_group_last_error(const pt_group *g) { return g ? g->err.c_str() :
 int pt_group_size(const pt_group *g) { return g ? (int)g->members.size() : 0; }
 pt_context *pt_group_member(pt_group *g, int i) { return g && i >= 0 && (size_t)i < g->members.size() ? g->members[(size_t)i] : nullptr; }
 
+// fn(member) on every member, each on a host thread of its own; the first failure (in member order) is reported
+// after all have finished, so that no member is left half-way while another is still working.
+template <class Fn>
+static int for_each_member(pt_group *g, Fn &&fn) {
+    const size_t n = g->members.size();
+    std::vector<int> rcs(n, PT_OK);
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < n; i++) pool.emplace_back([&, i] { rcs[i] = fn(g->members[i]); });
+    rcs[0] = fn(g->members[0]);
+    for (auto &t : pool) t.join();
+    for (size_t i = 0; i < n; i++)
+        if (rcs[i]) return member_fail(g, i, rcs[i]);
+    return PT_OK;
+}
+
 int pt_group_set_option(pt_group *g, int key, double value) {
     if (!g) return PT_ERR_INVALID;
-    for (size_t i = 0; i < g->members.size(); i++)
-        if (int rc = pt_set_option(g->members[i], key, value)) return member_fail(g, i, rc);
-    return PT_OK;
+    // an option value is either valid for every member or for none (they are the same library on the same kind of
+    // device), so a failure leaves no member changed
+    return for_each_member(g, [&](pt_context *c) { return pt_set_option(c, key, value); });
 }
 
 int pt_group_upload_scene(pt_group *g, const pt_scene_desc *scene) {
     if (!g) return PT_ERR_INVALID;
     // every GPU holds the whole scene (the largest benchmark scene is under 200 MB)
-    std::vector<int> rcs(g->members.size(), PT_OK);
-    std::vector<std::thread> pool;
-    for (size_t i = 1; i < g->members.size(); i++) pool.emplace_back([&, i] { rcs[i] = pt_upload_scene(g->members[i], scene); });
-    rcs[0] = pt_upload_scene(g->members[0], scene);
-    for (auto &t : pool) t.join();
-    for (size_t i = 0; i < rcs.size(); i++)
-        if (rcs[i]) return member_fail(g, i, rcs[i]);
-    return PT_OK;
+    return for_each_member(g, [&](pt_context *c) { return pt_upload_scene(c, scene); });
 }
 
 int pt_group_set_camera(pt_group *g, const pt_camera_desc *camera) {
     if (!g) return PT_ERR_INVALID;
-    for (size_t i = 0; i < g->members.size(); i++)
-        if (int rc = pt_set_camera(g->members[i], camera)) return member_fail(g, i, rc);
+    if (int rc = for_each_member(g, [&](pt_context *c) { return pt_set_camera(c, camera); })) {
+        g->film_pixels_valid = false;  // some members may have the new camera and some not: the group has none
+        return rc;
+    }
+    g->film_pixels_valid = true;
     const uint64_t npix = ptc_npix(g->members[0]);
     if (npix != g->film_pixels) {
         if (hipSetDevice(g->devices[0]) != hipSuccess) return gfail(g, PT_ERR_HIP, "hipSetDevice(%d) failed", g->devices[0]);
@@ -198,7 +243,7 @@ int pt_group_set_camera(pt_group *g, const pt_camera_desc *camera) {
         g->reduced = g->staging = nullptr;
         g->film_pixels = 0;
         hipError_t e = hipMalloc((void **)&g->reduced, npix * 3 * sizeof(float));
-        if (e == hipSuccess && !g->distinct) e = hipMalloc((void **)&g->staging, npix * 3 * sizeof(float));
+        if (e == hipSuccess && !g->use_rccl && g->members.size() > 1) e = hipMalloc((void **)&g->staging, npix * 3 * sizeof(float));
         if (e != hipSuccess) {
             if (g->reduced) (void)hipFree(g->reduced);
             g->reduced = nullptr;
@@ -232,14 +277,12 @@ int pt_group_render(pt_group *g, uint32_t stratum_begin, uint32_t stratum_end, u
 
 int pt_group_sync(pt_group *g) {
     if (!g) return PT_ERR_INVALID;
-    for (size_t i = 0; i < g->members.size(); i++)
-        if (int rc = pt_sync(g->members[i])) return member_fail(g, i, rc);
-    return PT_OK;
+    return for_each_member(g, [](pt_context *c) { return pt_sync(c); });
 }
 
 // Sum of the members' accumulators into g->reduced on the first member's device; *n_samples = passes in it.
 static int merge(pt_group *g, uint32_t *n_samples) {
-    if (!g->film_pixels) return gfail(g, PT_ERR_STATE, "no camera set");
+    if (!g->film_pixels || !g->film_pixels_valid) return gfail(g, PT_ERR_STATE, "no camera set");
     if (int rc = pt_group_sync(g)) return rc;
     const size_t count = (size_t)g->film_pixels * 3;
     uint32_t total = 0;
@@ -251,14 +294,20 @@ static int merge(pt_group *g, uint32_t *n_samples) {
         hipError_t e_ = (expr);                                                                             \
         if (e_ != hipSuccess) return gfail(g, PT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
     } while (0)
-    if (g->distinct) {
+    if (g->use_rccl) {
+        if (int rc = rccl_wait(g)) return gfail(g, rc, "%s", g->rccl_err.c_str());
+        // whatever fails between GroupStart and GroupEnd, GroupEnd is still called: an open group would nest every
+        // later RCCL call of the process
         ncclResult_t e = g->rccl.GroupStart();
-        for (int i = 0; i < n && e == ncclSuccess; i++) {
-            G_HIP(hipSetDevice(g->devices[(size_t)i]));
+        hipError_t he = hipSuccess;
+        for (int i = 0; i < n && e == ncclSuccess && he == hipSuccess; i++) {
+            he = hipSetDevice(g->devices[(size_t)i]);
+            if (he != hipSuccess) break;
             pt_context *c = g->members[(size_t)i];
             e = g->rccl.Reduce(ptc_accum(c), i == 0 ? g->reduced : nullptr, count, ncclFloat, ncclSum, 0, g->comms[(size_t)i], ptc_stream(c));
         }
         const ncclResult_t e2 = g->rccl.GroupEnd();
+        if (he != hipSuccess) return gfail(g, PT_ERR_HIP, "hipSetDevice before ncclReduce failed: %s", hipGetErrorString(he));
         if (e == ncclSuccess) e = e2;
         if (e != ncclSuccess) return gfail(g, PT_ERR_HIP, "ncclReduce of the accumulators: %s", g->rccl.GetErrorString(e));
         for (int i = 0; i < n; i++) {
@@ -330,6 +379,10 @@ int pt_group_stats_get(pt_group *g, pt_stats *out) {
         out->other_ms = std::max(out->other_ms, s.other_ms);
         out->render_ms = std::max(out->render_ms, s.render_ms);
         out->host_wait_ms = std::max(out->host_wait_ms, s.host_wait_ms);
+        out->walk_ms = std::max(out->walk_ms, s.walk_ms);
+        out->packet_ms = std::max(out->packet_ms, s.packet_ms);
+        out->walk_launches += s.walk_launches;
+        out->packet_launches += s.packet_launches;
     }
     return PT_OK;
 }

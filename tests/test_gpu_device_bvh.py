@@ -171,3 +171,30 @@ def test_triangle_buffers_inside_instances_and_in_the_light_list():
     x, y = rh.read_accum()[0], rd.read_accum()[0]
     same = np.all(np.nan_to_num(x).view(np.uint32).reshape(-1, 3) == np.nan_to_num(y).view(np.uint32).reshape(-1, 3), axis=1)
     assert same.mean() > 0.99, f"{(~same).sum()} of {same.size} pixels differ"
+
+
+@pytest.mark.parametrize("bsdf_probability", [1.0, 0.5])
+def test_device_built_scene_renders_the_same_bits_however_early_batches_are_finished(bsdf_probability):
+    # PT_OPT_BATCH_TICKS on a scene whose triangle tree was built on the device: what is left of a batch is finished
+    # by one lane per path, which must walk that tree in the order the ray-drawing search walks it (1: never finished
+    # early, 2: after two launches, 0: learnt); with BSDF_SAMPLE_PROBABILITY < 1 paths outlive max_depth as well
+    from pathtracer_amd.core import PT_OPT_BATCH_TICKS, PT_OPT_BSDF_SAMPLE_PROBABILITY, PT_OPT_ROLLING, HostScene, Renderer
+    src = scenes.knob(width=40, spp=36, max_depth=8, detail=0.25)
+    dev = HostScene(src, device_bvh_from=8)
+    assert dev.set_desc(0).tris.node_count == 0 and dev.set_desc(0).tris.prim_count > 3000
+    ref = None
+    for rolling, ticks in ((0, 1), (1 << 22, 1), (1 << 22, 2), (1 << 22, 3), (1 << 22, 0), (3 * 40 * 40, 2)):
+        r = Renderer(dev, device=0)
+        r.set_option(PT_OPT_ROLLING, rolling)
+        r.set_option(PT_OPT_BATCH_TICKS, ticks)
+        r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, bsdf_probability)
+        r.render(0, 20, seed=5)
+        r.sync()
+        r.render(20, 36, seed=5)
+        acc, n = r.read_accum()
+        assert n == 36
+        if ref is None:
+            ref = acc
+        else:
+            assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"rolling={rolling} ticks={ticks}"
+        r.close()

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from pathtracer_amd.scene_src import CameraSrc, SceneSource
-from tests.util import bits_equal
+from tests.util import bits_equal, samples_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -26,8 +26,7 @@ def _same_image(src, strata, seed=3):
     ref = np.nan_to_num(o.render(0, strata, seed=seed, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, strata, seed=seed), nan=0.0, posinf=0.0, neginf=0.0)
     assert got.shape == ref.shape
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() >= 0.99, close.mean()
+    samples_agree(got, ref, 0.999, "")
     # the accumulating entry point (launches shared between batches) adds up exactly these samples, in stratum
     # order, without the ones that are NaN (src/camera.rs:199, :212-217)
     raw = r.render_samples(0, strata, seed=seed)
@@ -172,8 +171,7 @@ def test_corners_of_ray_color(which, prob):
     r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, prob)
     ref = np.nan_to_num(o.render(0, 16, seed=9, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 16, seed=9), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() >= 0.99, (which, prob, close.mean())
+    samples_agree(got, ref, 0.999, (which, prob))
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
     r.stats_reset()
     r.render(0, 16, seed=9)
@@ -187,8 +185,7 @@ def test_the_same_corners_under_next_event_estimation(which):
     r.set_option(PT_OPT_INTEGRATOR, 1)
     ref = np.nan_to_num(o.render(0, 16, seed=9, iterative=2, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 16, seed=9), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() >= 0.99, (which, close.mean())
+    samples_agree(got, ref, 0.999, (which,))
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
 
 
@@ -325,6 +322,5 @@ def test_media_and_motion_with_rays_aimed_at_the_light(which):
     r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, 0.6)
     ref = np.nan_to_num(o.render(0, 16, seed=2, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 16, seed=2), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() >= 0.99, (which, close.mean())
+    samples_agree(got, ref, 0.999, (which,))
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)

@@ -25,7 +25,8 @@ def _member_accum(g: GroupRenderer, i: int):
     return acc, int(n.value)
 
 
-def test_group_of_one_equals_a_context_bit_for_bit(host):
+def test_group_of_one_equals_a_context_bit_for_bit(host, monkeypatch):
+    monkeypatch.setenv("PT_GROUP_RCCL_ALWAYS", "1")  # a group of one needs no collective: ask for the one-rank reduce all the same
     r = Renderer(host, device=0)
     r.render(0, 40, seed=5)
     want, n_want = r.read_accum()
@@ -39,6 +40,12 @@ def test_group_of_one_equals_a_context_bit_for_bit(host):
     assert np.array_equal(g.read_rgb8(), img_want)
     st = g.stats()
     assert st["paths"] == 40 * g.npix and st["rays"] >= st["paths"]
+    g.close()
+    monkeypatch.delenv("PT_GROUP_RCCL_ALWAYS")
+    g = GroupRenderer(host, [0])  # and without it: the merge is a copy
+    g.render(0, 40, seed=5)
+    got, n = g.read_accum()
+    assert n == 40 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
     g.close()
     r.close()
 
@@ -93,3 +100,20 @@ def test_group_renders_progressively_and_resets(host):
     assert n0 == 0 and not zero.any()
     g.close()
     h.close()
+
+
+def test_members_are_created_side_by_side(host):
+    """pt_group_create makes its contexts on one host thread each: four members on one GPU take about as long as one
+    context, not four times as long (slack for a loaded box)."""
+    import time
+    Renderer(host, device=0).close()  # the runtime and the code object are loaded by now
+    t0 = time.perf_counter()
+    r = Renderer(host, device=0)
+    one = time.perf_counter() - t0
+    r.close()
+    t0 = time.perf_counter()
+    g = GroupRenderer(host, [0, 0, 0, 0])
+    four = time.perf_counter() - t0
+    assert g.size() == 4
+    g.close()
+    assert four <= 2.0 * one + 0.25, f"one context {one:.3f} s, a group of four {four:.3f} s"

@@ -8,6 +8,7 @@ import pytest
 
 from pathtracer_amd import scenes
 from pathtracer_amd.scene_src import CameraSrc, SceneSource
+from tests.util import samples_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -152,6 +153,5 @@ def test_rendering_with_more_lights_than_the_flat_scan_takes(integrator):
         ref = o.render(0, 4, seed=8, iterative=True, per_sample=True)["per_sample"]
     ref = np.nan_to_num(ref, nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 4, seed=8), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() > 0.99, close.mean()
+    samples_agree(got, ref, 0.999, "")
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)

@@ -27,7 +27,7 @@ import pytest
 from pathtracer_amd import scenes
 from pathtracer_amd.core import PROBE_IN_DTYPE, HostScene, Renderer
 from pathtracer_amd.scene_src import CameraSrc, SceneSource
-from tests.util import ulp_diff
+from tests.util import ulp_diff, samples_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -246,8 +246,7 @@ def test_frame_filling_sphere_per_sample_radiance(material):
         assert np.array_equal(np.isnan(got), np.isnan(want)) or np.mean(np.isnan(got) != np.isnan(want)) < 1e-3
         g = np.nan_to_num(got, nan=0.0, posinf=0.0, neginf=0.0)
         w = np.nan_to_num(want, nan=0.0, posinf=0.0, neginf=0.0)
-        close = np.all(np.abs(g - w) <= 1e-3 * np.maximum(1.0, np.abs(w)), axis=-1)
-        assert close.mean() > 0.999, f"{material}: only {close.mean():.5f} of the samples agree"
+        samples_agree(g, w, 0.999, material)
         assert np.abs(w).sum() > 0.0
     finally:
         r.close()

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from pathtracer_amd import scenes
-from tests.util import image_errors
+from tests.util import image_errors, samples_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -29,8 +29,7 @@ def test_per_sample_radiance_against_the_oracles_statement(name):
     o, r = _pair(SCENES[name](16))
     ref = np.nan_to_num(o.render(0, 6, seed=13, iterative=NEE, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 6, seed=13), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() > 0.99, close.mean()
+    samples_agree(got, ref, 0.999, "")
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
 
 

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from pathtracer_amd import scenes
-from tests.util import bits_equal, image_errors
+from tests.util import bits_equal, image_errors, samples_agree
 
 pytestmark = pytest.mark.gpu
 
@@ -90,8 +90,7 @@ def test_per_sample_radiance_with_and_without_light_sampling(name, prob):
     r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, prob)
     ref = np.nan_to_num(o.render(0, 6, seed=13, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 6, seed=13), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() > 0.99, close.mean()
+    samples_agree(got, ref, 0.999, "")
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
 
 
@@ -235,8 +234,7 @@ def test_vertices_inside_a_sphere_light_poison_their_paths_as_in_the_reference()
     got = r.render_samples(0, 6, seed=3)
     assert np.array_equal(np.isnan(ref), np.isnan(got))
     ref, got = np.nan_to_num(ref), np.nan_to_num(got)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() > 0.995, close.mean()
+    samples_agree(got, ref, 0.999, "")
     assert ref.sum() > 0
 
 
@@ -252,8 +250,7 @@ def test_paths_that_outlive_max_depth_under_light_sampling(name, depth, prob):
     r.set_option(PT_OPT_BSDF_SAMPLE_PROBABILITY, prob)
     ref = np.nan_to_num(o.render(0, 6, seed=13, iterative=False, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 6, seed=13), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() > 0.99, close.mean()
+    samples_agree(got, ref, 0.999, "")
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
     accs = []
     rays = []

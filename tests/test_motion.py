@@ -5,6 +5,7 @@ import pytest
 
 from pathtracer_amd import scenes
 from pathtracer_amd.scene_src import CameraSrc, SceneSource
+from tests.util import samples_agree
 
 
 def _scene(c0, c1, width=48, spp=64, depth=1, extras=False):
@@ -62,8 +63,7 @@ def test_device_restatement_against_the_oracle_per_sample(which):
     o, r = OracleScene(src), Renderer(HostScene(src))
     ref = np.nan_to_num(o.render(0, 4, seed=5, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
     got = np.nan_to_num(r.render_samples(0, 4, seed=5), nan=0.0, posinf=0.0, neginf=0.0)
-    close = np.all(np.abs(got - ref) <= 1e-3 * np.maximum(1.0, np.abs(ref)), axis=-1)
-    assert close.mean() > 0.99, close.mean()
+    samples_agree(got, ref, 0.999, "")
     assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
     accs = []
     for pipes, rolling in ((1, 0), (2, 3 * 40 * 40)):

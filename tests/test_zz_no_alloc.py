@@ -127,3 +127,45 @@ def test_static_first_hits_while_a_render_is_in_flight():
         d_rays.free()
         d_out.free()
         r.close()
+
+
+def test_two_contexts_on_two_threads_take_turns_on_the_shared_array():
+    """Every context of a GPU uses the same fixed array; the library lets one call at a time through, so two host
+    threads that call at once each get the hits they get alone."""
+    import threading
+    src_a, src_b = scenes.cornell(width=96, spp=4, max_depth=8), scenes.knob(width=96, spp=4, detail=0.25)
+    ra, rb = Renderer(HostScene(src_a), device=0), Renderer(HostScene(src_b), device=0)
+    n = 150_000
+    rays_a = _rays(ra.generate_rays(0, seed=3), n, 5)
+    rays_b = _rays(rb.generate_rays(0, seed=3), n, 6)
+    rays_b[n // 2:, :6] *= 0.05
+    want_a, want_b = ra.trace(rays_a), rb.trace(rays_b)
+    bufs = [DeviceBuffer(n * 32), DeviceBuffer(n * HIT_DTYPE.itemsize), DeviceBuffer(n * 32), DeviceBuffer(n * HIT_DTYPE.itemsize)]
+    try:
+        bufs[0].upload(rays_a)
+        bufs[2].upload(rays_b)
+        errors = []
+
+        def work(r, d_rays, d_out, want, rounds=6):
+            try:
+                for _ in range(rounds):
+                    d_out.fill(0xAB)
+                    r.trace_static(d_rays.ptr.value, n, d_out.ptr.value)
+                    got = d_out.download(n, HIT_DTYPE)
+                    if not np.array_equal(got.view(np.uint8), want.view(np.uint8)):
+                        errors.append("hits differ")
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        ta = threading.Thread(target=work, args=(ra, bufs[0], bufs[1], want_a))
+        tb = threading.Thread(target=work, args=(rb, bufs[2], bufs[3], want_b))
+        ta.start()
+        tb.start()
+        ta.join()
+        tb.join()
+        assert not errors, errors
+    finally:
+        for b in bufs:
+            b.free()
+        ra.close()
+        rb.close()

@@ -31,12 +31,12 @@ def bench_line(name):
     raise SystemExit(f"no bench line in {name}.log")
 
 
-def totals(name):
+def totals(name, only=None):
     tot = defaultdict(float)
     dur = {}
     with open(os.path.join(root, name, f"{name}_counter_collection.csv"), newline="") as f:
         for r in csv.DictReader(f):
-            if any(k in r["Kernel_Name"] for k in kernels):
+            if any(k in r["Kernel_Name"] for k in (kernels if only is None else (only,))):
                 tot[r["Counter_Name"]] += float(r["Counter_Value"])
                 dur[int(r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     return tot, len(dur), sum(dur.values()) * 1e-9
@@ -97,6 +97,46 @@ res = {
     "raw": {k: v for k, (v, _) in sorted(c.items())},
 }
 res["hbm_bytes_per_ray"] = res["fetch_bytes_per_ray"] + res["write_bytes_per_ray"]
+
+# each kernel on its own: the camera-ray kernel traces the paths that start (bench line: "paths"), the ray-drawing
+# kernel everything else (everything, where the camera rays have no kernel of their own)
+per_kernel = {}
+for kname in kernels:
+    k = {}
+    ok = True
+    for p in PASSES:
+        t, n, secs_k = totals(p, kname)
+        if n == 0:
+            ok = False
+            break
+        b = lines[p]
+        paths = float(b.get("paths", b["rays"] / b["mean_path_length"]))
+        has_packet = totals(p, "k_extend_packet")[1] > 0
+        r_k = paths if kname == "k_extend_packet" else (float(b["rays"]) - paths if has_packet else float(b["rays"]))
+        k[p] = (t, n, secs_k, r_k)
+    if not ok:
+        continue
+    g = lambda p, name: k[p][0][name]
+    per_kernel[kname] = {
+        "dispatches": k["sq_time"][1], "rays": k["sq_time"][3], "kernel_seconds_serialised": k["sq_time"][2],
+        "grays_per_s_serialised": k["sq_time"][3] / k["sq_time"][2] / 1e9,
+        "valu_per_ray": g("sq_insts", "SQ_INSTS_VALU") / k["sq_insts"][3], "salu_per_ray": g("sq_insts", "SQ_INSTS_SALU") / k["sq_insts"][3],
+        "vmem_rd_per_ray": g("sq_insts", "SQ_INSTS_VMEM_RD") / k["sq_insts"][3], "smem_per_ray": g("sq_insts", "SQ_INSTS_SMEM") / k["sq_insts"][3],
+        "lds_per_ray": g("sq_insts", "SQ_INSTS_LDS") / k["sq_insts"][3],
+        "lane_util": g("sq_time", "SQ_THREAD_CYCLES_VALU") / (64.0 * g("sq_time", "SQ_ACTIVE_INST_VALU")),
+        "wait_share_of_wave_cycles": g("sq_time", "SQ_WAIT_ANY") / g("sq_time", "SQ_WAVE_CYCLES"),
+        "l1_hit": 1.0 - g("cache", "TCP_TCC_READ_REQ_sum") / g("cache", "TCP_TOTAL_CACHE_ACCESSES_sum"),
+        "l2_hit": g("cache", "TCC_HIT_sum") / (g("cache", "TCC_HIT_sum") + g("cache", "TCC_MISS_sum")),
+        "l2_read_latency_cycles": g("cache", "TCP_TCC_READ_REQ_LATENCY_sum") / max(1.0, g("cache", "TCP_TCC_READ_REQ_sum")),
+        "hbm_bytes_per_ray": 2.0 * g("fetch", "FETCH_SIZE") * 1024.0 / k["fetch"][3] + g("write", "WRITE_SIZE") * 1024.0 / k["write"][3],
+    }
+res["per_kernel"] = per_kernel
+res["csrc_sha256"] = b0.get("csrc_sha256")
+try:
+    import subprocess
+    res["git_commit"] = subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    res["git_commit"] = None
 with open(out, "w") as f:
     json.dump(res, f, indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "raw"}, indent=1))
