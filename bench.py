@@ -254,9 +254,9 @@ def main():
         per_kernel = {}
         if st["packet_launches"]:
             kernels = (("k_extend_packet", st["paths"], st["packet_ms"], st["packet_launches"], b_ray_cam, "the paths that start with a step (camera rays), a wave at a time"),
-                       ("k_extend_walk", st["rays"] - st["paths"], st["walk_ms"], st["walk_launches"], b_ray_bounce, "the rays queued by earlier steps (later bounces), drawn by persistent waves"))
+                       ("k_extend_walk", st["rays"] - st["paths"] - st["shadow_rays"], st["walk_ms"], st["walk_launches"], b_ray_bounce, "the rays queued by earlier steps (later bounces), drawn by persistent waves"))
         else:
-            kernels = (("k_extend_walk", st["rays"], st["walk_ms"], st["walk_launches"], b_ray, "all rays of a step, drawn by persistent waves (the camera rays have no kernel of their own in this configuration)"),)
+            kernels = (("k_extend_walk", st["rays"] - st["shadow_rays"], st["walk_ms"], st["walk_launches"], b_ray, "all rays of a step, drawn by persistent waves (the camera rays have no kernel of their own in this configuration)"),)
         for kname, krays, kms, kn, kb, what in kernels:
             if kms > 0 and kn:
                 a = krays * kb / (kms * 1e-3) / 1e9
@@ -299,6 +299,7 @@ def main():
             "paths_per_s": paths_all / dt,
             "rays": rays_all,
             "paths": paths_all,
+            "shadow_rays": st["shadow_rays"],
             "mean_path_length": rays_all / max(1.0, paths_all),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,

@@ -224,6 +224,7 @@ pub struct pt_stats {
     pub packet_ms: f64,
     pub walk_launches: u64,
     pub packet_launches: u64,
+    pub shadow_rays: u64,
 }
 
 #[repr(C)]

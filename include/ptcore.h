@@ -166,6 +166,7 @@ typedef struct pt_stats {
                                  have no kernel of their own) */
     double packet_ms;         /* the camera-ray kernel: the paths that start with the step, a wave at a time */
     uint64_t walk_launches, packet_launches; /* launches those times are summed over */
+    uint64_t shadow_rays;     /* of `rays`: the shadow rays of PT_OPT_INTEGRATOR = 1 (traced by a kernel of their own) */
 } pt_stats;
 
 enum {

@@ -666,10 +666,12 @@ struct LightBuffer {
         if (i < nt + ns + nq) return objects.quads.buffer[i - nt - ns].sample(rng, origin);
         return v3(0, 0, 0);  // Instance uses the trait default (:100-102)
     }
-    V3 sample_nee(Rng &rng, V3 origin) const {  // the same with Sphere::sample_towards
+    // the same with Sphere::sample_towards.  *picked: the index of the light that was drawn
+    V3 sample_nee(Rng &rng, V3 origin, size_t *picked = nullptr) const {
         size_t n = objects.len();
         size_t i = (size_t)rng.below(n);
         size_t nt = objects.triangles.len(), ns = objects.spheres.len(), nq = objects.quads.len();
+        if (picked) *picked = i;
         if (i < nt) return objects.triangles.buffer[i].sample(rng, origin);
         if (i < nt + ns) return objects.spheres.buffer[i - nt].sample_towards(rng, origin);
         if (i < nt + ns + nq) return objects.quads.buffer[i - nt - ns].sample(rng, origin);
@@ -681,6 +683,28 @@ struct LightBuffer {
         for (const auto &s : objects.spheres.buffer) pdf += s.pdf(ray);
         for (const auto &q : objects.quads.buffer) pdf += q.pdf(ray);
         for (size_t i = 0; i < objects.instances.len(); i++) pdf += 0.0f;  // trait default (:97-99)
+        return pdf / (float)objects.len();
+    }
+    // Light i's own density over directions for the ray (Triangle::pdf_solid_angle, Sphere::pdf, Quad::pdf; 0 when the
+    // ray misses it or for an instance), and where the ray meets that light.
+    float term_nee(size_t i, const Ray &ray, HitRecord &rec) const {
+        size_t nt = objects.triangles.len(), ns = objects.spheres.len(), nq = objects.quads.len();
+        Ray r = ray;
+        if (i < nt) return objects.triangles.buffer[i].hit(r, rec) ? objects.triangles.buffer[i].pdf_solid_angle(ray) : 0.0f;
+        if (i < nt + ns) return objects.spheres.buffer[i - nt].hit(r, rec) ? objects.spheres.buffer[i - nt].pdf(ray) : 0.0f;
+        if (i < nt + ns + nq) return objects.quads.buffer[i - nt - ns].hit(r, rec) ? objects.quads.buffer[i - nt - ns].pdf(ray) : 0.0f;
+        return 0.0f;
+    }
+    static bool same_distance(float a, float b) { return std::fabs(a - b) <= 1.0e-4f * rmax(1.0f, std::fabs(b)); }
+    // The density with which light sampling yields the point the ray reaches at distance t_hit: the terms of the
+    // lights the ray meets at that distance (the emitter that was hit, as a light), over the number of lights.
+    float pdf_nee_at(const Ray &ray, float t_hit) const {
+        float pdf = 0.0f;
+        HitRecord rec;
+        for (size_t i = 0; i < objects.len(); i++) {
+            float term = term_nee(i, ray, rec);
+            if (term != 0.0f && same_distance(rec.t, t_hit)) pdf += term;
+        }
         return pdf / (float)objects.len();
     }
     float pdf_nee(const Ray &ray) const {  // the same with Triangle::pdf_solid_angle

@@ -154,6 +154,26 @@ struct Scene {
         t_event = best;
         return any;
     }
+    // The share of light that gets from the ray's origin to t_end without scattering (next-event estimation:
+    // shadow rays are not scattered, they are dimmed): exp(-sum of density x length inside each medium).
+    float transmittance(const Ray &ray, float t_end) const {
+        float tau = 0.0f;
+        for (const pts_medium &md : media) {
+            V3 oc = v3(md.center[0], md.center[1], md.center[2]) - ray.origin;
+            float a = norm_squared(ray.direction);
+            float h = dot(ray.direction, oc);
+            float c = norm_squared(oc) - md.radius * md.radius;
+            float disc = h * h - a * c;
+            if (!(disc >= 0.0f)) continue;
+            float sq = std::sqrt(disc);
+            float t1 = (h - sq) / a, t2 = (h + sq) / a;
+            if (t1 < ray.t_min) t1 = ray.t_min;
+            if (t2 > t_end) t2 = t_end;
+            if (!(t1 < t2)) continue;
+            tau = tau + md.density * ((t2 - t1) * std::sqrt(a));
+        }
+        return std::exp(-tau);
+    }
     // The ray that leaves a scattering event in medium `which` at p: uniform on the sphere, two draws.
     Ray medium_scatter(Rng &rng, int which, V3 p, Color &albedo) const {
         albedo = textures.value(media[(size_t)which].texture, 0.0f, 0.0f, p);
@@ -306,6 +326,14 @@ struct Scene {
     // statement, operation for operation, of the estimator PT_OPT_INTEGRATOR = 1 of the device library
     // runs.  Radiance is summed along the path in the order it is found.  prev_pdf: density with which
     // the current ray was drawn at a vertex with light sampling, 0 otherwise.
+    // Light sampling picks one light and a point on it; the sample counts with that light's own density over
+    // directions (divided by the number of lights) and the light's emitted radiance where the ray meets it, if
+    // nothing lies between the vertex and that point: the shadow ray ends just short of the light (SHADOW_REACH x the
+    // distance) and any hit along it blocks the sample.  An emitter that a BSDF-sampled ray finds is weighted
+    // against the density with which light sampling yields that very point (pdf_nee_at).  Participating media
+    // scatter the path's own rays as in ray_color (no light is sampled at such an event) and dim the shadow rays
+    // by their transmittance; moving spheres are where they are at the path's time for both kinds of ray.
+    static constexpr float SHADOW_REACH = 0.999f;
     Color ray_color_nee(Rng &rng, Ray ray, uint32_t max_depth, uint64_t *rays) const {
         Color L = gray(0.0f), beta = gray(1.0f);
         float prev_pdf = 0.0f;
@@ -314,7 +342,21 @@ struct Scene {
             if (depth == 0) return L;
             if (rays) (*rays)++;
             HitRecord rec;
-            if (!objects.hit(ray, rec)) return L + cmul(beta, camera.background);
+            const bool any_hit = hit_scene(rng, ray, rec);
+            if (!media.empty()) {
+                float t_event;
+                int which = 0;
+                if (medium_event(rng, ray, any_hit ? rec.t : INFINITY, t_event, which)) {
+                    Color albedo;
+                    Ray next = medium_scatter(rng, which, ray.at(t_event), albedo);
+                    beta = cmul(beta, albedo);
+                    ray = next;
+                    prev_pdf = 0.0f;
+                    depth -= 1;
+                    continue;
+                }
+            }
+            if (!any_hit) return L + cmul(beta, camera.background);
             const Material *material = mat(rec.material);
             if (!material) return L;
             if (material->is_emissive()) {
@@ -322,7 +364,7 @@ struct Scene {
                 // the density with which light sampling draws this direction, whatever lies along it: a fresh ray, since
                 // `ray` now ends at the emitter and a light behind it would no longer count
                 if (lights.objects.len() != 0 && prev_pdf > 0.0f && prev_pdf < INFINITY)
-                    w = prev_pdf / (prev_pdf + lights.pdf_nee(Ray::make(ray.origin, ray.direction)));
+                    w = prev_pdf / (prev_pdf + lights.pdf_nee_at(Ray::make(ray.origin, ray.direction), rec.t));
                 return L + cmul(beta, shading.emitted(*material, rec)) * w;
             }
             ONB surface = ONB::make(rec.normal);
@@ -356,20 +398,28 @@ struct Scene {
                 continue;
             }
             if (lights.objects.len() != 0) {
-                V3 ls = lights.sample_nee(rng, rec.p);
+                size_t picked = 0;
+                V3 ls = lights.sample_nee(rng, rec.p, &picked);
                 Ray shadow = Ray::make(rec.p, ls);
-                float lp = lights.pdf_nee(shadow);
+                HitRecord lrec;
+                float lp = lights.term_nee(picked, shadow, lrec) / (float)lights.objects.len();
                 if (lp > 0.0f && lp < INFINITY) {
                     V3 wl = normalize(surface.to_local(ls));
                     float sp = shading.scattering_pdf(*material, w_out, wl, rec);
                     if (sp > 0.0f) {
                         Color f = shading.bsdf_evaluate(*material, w_out, wl, rec) * std::fabs(wl.y);
                         Color c = cmul(beta, f) / (lp + sp);
-                        if (rays) (*rays)++;
-                        HitRecord srec;
-                        if (objects.hit(shadow, srec)) {
-                            const Material *m2 = mat(srec.material);
-                            if (m2 && m2->is_emissive() && srec.front_face) L = L + cmul(c, shading.emitted(*m2, srec));
+                        const Material *lm = mat(lrec.material);
+                        Color le = (lm && lm->is_emissive()) ? shading.emitted(*lm, lrec) : gray(0.0f);
+                        if (le.x != 0.0f || le.y != 0.0f || le.z != 0.0f) {
+                            if (rays) (*rays)++;
+                            shadow.t_max = lrec.t * SHADOW_REACH;
+                            HitRecord srec;
+                            if (!hit_scene(rng, shadow, srec)) {
+                                Color add = cmul(c, le);
+                                if (!media.empty()) add = add * transmittance(shadow, shadow.t_max);
+                                L = L + add;
+                            }
                         }
                     }
                 }

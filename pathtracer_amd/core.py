@@ -81,7 +81,7 @@ class pt_stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("extend_launches", C.c_uint64), ("extend_ms", C.c_double),
                 ("extend_busy_ms", C.c_double), ("shade_ms", C.c_double), ("other_ms", C.c_double), ("render_ms", C.c_double), ("host_wait_ms", C.c_double), ("node_tests", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("quad_tests", C.c_uint64), ("device_bytes", C.c_uint64),
-                ("bad_refs", C.c_uint64), ("walk_ms", C.c_double), ("packet_ms", C.c_double), ("walk_launches", C.c_uint64), ("packet_launches", C.c_uint64)]
+                ("bad_refs", C.c_uint64), ("walk_ms", C.c_double), ("packet_ms", C.c_double), ("walk_launches", C.c_uint64), ("packet_launches", C.c_uint64), ("shadow_rays", C.c_uint64)]
 
 
 PT_PRIM_TRI, PT_PRIM_SPHERE, PT_PRIM_QUAD = 0, 1, 2  # pt_hit::prim_type

@@ -21,6 +21,7 @@ struct DevStats {
     // many passes, [2..7] state of the first such lane
     unsigned long long bad_refs[8];
     unsigned long long queue_overflow;  // queue entries dropped for want of room (wave_push)
+    unsigned long long shadow_rays;     // of rays_total: shadow rays of the next-event estimator
 };
 
 struct BatchParams {
@@ -45,35 +46,6 @@ __device__ __forceinline__ void path_sample(const PathState &ps, uint32_t slot, 
     stratum = rp.stratum_first + (local - pixel * rp.n_strata);
     seed_mixed = rp.seed_mixed;
 }
-
-// Work handed out as the waves get to it.  Block b of the work is on list b mod WORK_LISTS; a wave draws from the
-// list of its XCD (a counter on a line of its own) and, when that is used up, from the next ones.  All XCDs
-// sweep the work together from its start to its end, whatever the number of workgroups a CU holds at once and
-// whenever they start: what is read and written at any one time lies close together, and results are appended
-// to the queues nearly in the order of the work.  `cursors`: WORK_LISTS control words, CTL_STRIDE apart, zero
-// before the launch.
-struct BlockClaim {
-    uint32_t *cursors;
-    uint32_t n_blocks, list, lists_left;
-    __device__ __forceinline__ void init(uint32_t *c, uint32_t n) {
-        cursors = c;
-        n_blocks = n;
-        list = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % WORK_LISTS;  // HW_REG_XCC_ID[3:0]
-        lists_left = WORK_LISTS;
-    }
-    // the next block for this wave (the same value in every lane); false when the work is used up
-    __device__ __forceinline__ bool next(uint32_t &block) {
-        while (lists_left != 0u) {
-            uint32_t got = 0u;
-            if (lane_id() == 0u) got = atomicAdd(&cursors[list * CTL_STRIDE], 1u);
-            block = (uint32_t)__builtin_amdgcn_readfirstlane((int)got) * WORK_LISTS + list;
-            if (block < n_blocks) return true;
-            lists_left--;
-            list = (list + 1u) % WORK_LISTS;
-        }
-        return false;
-    }
-};
 
 // Open chunks of the material queues, one set per wave of the workgroup, kept in LDS
 // because their number is only known at run time.  Only the owning wave touches its row.
@@ -260,8 +232,10 @@ __device__ __forceinline__ void extend_prologue(const PathState &ps, uint32_t bo
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const uint32_t parity = bounce & 1u;
         ps.ctl[(CTL_RAY_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        ps.ctl[(CTL_RAY_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        for (uint32_t l = 0; l < WORK_LISTS; l++) ps.ctl[(CTL_PACKET_CURSOR + WORK_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
+        for (uint32_t l = 0; l < WORK_LISTS; l++) {
+            ps.ctl[(CTL_PACKET_CURSOR + WORK_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
+            ps.ctl[(CTL_WALK_CURSOR + WORK_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
+        }
         if (n_chunks + n_new) atomicAdd(&stats->extend_nonempty, 1ull);
         if (n_new) {  // the paths that start with this launch, and their camera rays
             atomicAdd(&stats->paths_total, (unsigned long long)n_new);
@@ -285,9 +259,19 @@ __device__ __forceinline__ void flush_counters(bool count, const TravCounters &t
 // three lines of PrimitiveBuffer::hit, src/objects.rs:192-194).
 // CLASSIFY: the scene has no instances, so this is the whole of PrimitiveBuffer::hit.
 // A scene with moving spheres (pts_moving_sphere) tests them last, where they are at the path's time.
+// The time of the path named by `slot`: a hash of its generator's key.
+__device__ __forceinline__ float path_time_of_slot(const PathState &ps, uint32_t slot) {
+    uint64_t seed_mixed;
+    uint32_t pixel, stratum;
+    path_sample(ps, slot, seed_mixed, pixel, stratum);
+    Rng rng;
+    rng.init(seed_mixed, pixel, stratum, 0u);
+    return path_time(rng.key);
+}
 template <class WL>
 __device__ __forceinline__ float path_time_at(const DevCamera &cam, const PathState &ps, const WL &wl, uint32_t pos) {
-    if (!wl.fresh(pos)) return ps.beta[wl.parity][pos].w;
+    // a queued ray carries its path's time in beta.w, unless that word holds a density (next-event estimation)
+    if (!wl.fresh(pos)) return ps.nee ? path_time_of_slot(ps, wl.slot(ps, pos)) : ps.beta[wl.parity][pos].w;
     f3 o, d;
     uint32_t draws;
     float time;
@@ -359,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
     st.init(ps.overflow, ps.overflow_stride);
     // a lane's ray is named by its position in the work list
     walk_world<INSTANCES>(
-        sc, n_pieces, &ps.ctl[(CTL_RAY_CURSOR + wl.parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+        sc, n_pieces, &ps.ctl[(CTL_WALK_CURSOR + WORK_LISTS * wl.parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &pos, TravRay &r) {
             if (wl.slot(ps, i) == QUEUE_EMPTY) return false;
             pos = i;
@@ -494,6 +478,7 @@ __global__ __launch_bounds__(BLOCK) void k_extend_inst(DevScene sc, DevCamera ca
     flush_counters(COUNT, tc, stats);
 }
 
+constexpr float SHADOW_REACH = 0.999f;  // a shadow ray ends this short of the light it is aimed at
 // What a vertex leaves behind: the path's next ray with what travels with it (alive), and with next-event
 // estimation possibly a shadow ray.
 struct VertexOut {
@@ -506,7 +491,7 @@ struct VertexOut {
 template <int MT, bool NEE>
 __device__ __forceinline__ void shade_surface(const DevScene &sc, const PathState &ps, const BatchParams &bp, uint32_t slot, VertexOut &out,
                                               f3 ro, f3 rd, float4 h4, float4 b4, uint32_t code, f3 beta, uint32_t depth, uint32_t rng_counter) {
-    const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code, NEE ? 0.0f : b4.w);
+    const Surf s = make_surf(sc, ro, rd, h4.x, h4.y, h4.z, __float_as_uint(h4.w), code, NEE ? (ps.moving ? path_time_of_slot(ps, slot) : 0.0f) : b4.w);
     const DevMaterial m = sc.mats[s.material];
     if constexpr (MT == PTS_MAT_DIFFUSE_LIGHT) {
         // Diffuse::emitted (light.rs:42-47); an emissive hit ends the path (camera.rs:288-290)
@@ -514,7 +499,8 @@ __device__ __forceinline__ void shade_surface(const DevScene &sc, const PathStat
         if (s.front_face) e = tex_value(sc, m.texture, s.u, s.v, s.p);
         if constexpr (NEE) {
             float w = 1.0f;
-            if (sc.n_light_total != 0u && b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true>(sc, ro, rd));
+            // against the density with which light sampling yields this very point: the terms of the lights the ray meets here
+            if (sc.n_light_total != 0u && b4.w > 0.0f && b4.w < INFINITY) w = b4.w / (b4.w + light_pdf<true, true>(sc, ro, rd, h4.x));
             const float4 c = ps.contrib[slot];
             const f3 add = cmul(beta, e) * w;
             ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
@@ -540,18 +526,31 @@ __device__ __forceinline__ void shade_surface(const DevScene &sc, const PathStat
             beta = cmul(beta, attenuation);
         } else if constexpr (NEE && (MT == PTS_MAT_LAMBERTIAN || MT == PTS_MAT_DISNEY_DIFFUSE || MT == PTS_MAT_DISNEY_SHEEN)) {
             if (sc.n_light_total != 0u) {
-                const f3 ls = light_sample<true>(sc, rng, s.p);
-                const float lp = light_pdf<true>(sc, s.p, ls);
+                // one light, a point on it; the sample counts with that light's own density over directions and its
+                // radiance where the ray meets it, if the shadow ray, which ends just short of it, hits nothing
+                uint32_t picked;
+                const f3 ls = light_sample<true>(sc, rng, s.p, &picked);
+                LightHit lh;
+                const float lp = light_term<true>(sc, picked, s.p, ls, &lh) / (float)sc.n_light_total;
                 if (lp > 0.0f && lp < INFINITY) {
                     const f3 wl = normalize(to_local(surface, ls));
                     const float sp = mat_pdf<MT>(m, w_out, wl, s);
                     if (sp > 0.0f) {
                         const f3 f = mat_eval<MT>(sc, m, w_out, wl, s) * fabsf(wl.y);
                         const f3 c = cmul(beta, f) / (lp + sp);
-                        out.shadow_o = make_float4(s.p.x, s.p.y, s.p.z, 0.0f);
-                        out.shadow_d = make_float4(ls.x, ls.y, ls.z, 0.0f);
-                        out.shadow_c = make_float4(c.x, c.y, c.z, 0.0f);
-                        out.shadow = true;
+                        const int32_t lmat = lh.type == PT_PRIM_TRI ? sc.tri_mat[lh.prim] : (lh.type == PT_PRIM_SPHERE ? sc.sphere_mat[lh.prim] : sc.quad_mat[lh.prim]);
+                        f3 le = mk3(0.0f, 0.0f, 0.0f);
+                        if (lmat >= 0 && sc.mats[lmat].type == PTS_MAT_DIFFUSE_LIGHT) {  // Diffuse::emitted (light.rs:42-47)
+                            const Surf sl = make_surf(sc, s.p, ls, lh.t, lh.u, lh.v, lh.prim, lh.type);
+                            if (sl.front_face) le = tex_value(sc, sc.mats[lmat].texture, sl.u, sl.v, sl.p);
+                        }
+                        if (le.x != 0.0f || le.y != 0.0f || le.z != 0.0f) {
+                            const f3 add = cmul(c, le);
+                            out.shadow_o = make_float4(s.p.x, s.p.y, s.p.z, 0.0f);
+                            out.shadow_d = make_float4(ls.x, ls.y, ls.z, lh.t * SHADOW_REACH);
+                            out.shadow_c = make_float4(add.x, add.y, add.z, 0.0f);
+                            out.shadow = true;
+                        }
                     }
                 }
             }
@@ -641,7 +640,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene &sc, const DevCamera
         float time;
         fresh_path(cam, ps, slot, ro, rd, rng_counter, time, ps.fresh_draws[pos - wl.queued]);
         depth = cam.max_depth;
-        b4 = make_float4(1.0f, 1.0f, 1.0f, time);
+        b4 = make_float4(1.0f, 1.0f, 1.0f, NEE ? 0.0f : time);  // w: the path's time, or the density the ray was drawn with (none)
     } else {
         const float4 ro4 = ps.ray_o[wl.parity][pos], rd4 = ps.ray_d[wl.parity][pos];
         ro = mk3(ro4.x, ro4.y, ro4.z);
@@ -670,19 +669,26 @@ __device__ __forceinline__ void shade_vertex(const DevScene &sc, const DevCamera
             beta = cmul(beta, albedo);
             depth -= 1u;
             if (depth == 0u) {
-                ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
+                if constexpr (!NEE) ps.contrib[slot] = make_float4(beta.x * 0.0f, beta.y * 0.0f, beta.z * 0.0f, 0.0f);
                 return;
             }
             out.ray_o = make_float4(p.x, p.y, p.z, __uint_as_float(rng.counter));
             out.ray_d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(depth));
-            out.beta = make_float4(beta.x, beta.y, beta.z, b4.w);
+            out.beta = make_float4(beta.x, beta.y, beta.z, NEE ? 0.0f : b4.w);  // no light is sampled at a scattering event
             out.alive = true;
             return;
         }
         rng_counter = rng.counter;
         if constexpr (MT == PTD_MAT_MEDIUM) {  // nothing to shade: src/camera.rs:371, :277-283
             const f3 l = missed ? bp.background : mk3(0.0f, 0.0f, 0.0f);
-            ps.contrib[slot] = make_float4(beta.x * l.x, beta.y * l.y, beta.z * l.z, 0.0f);
+            if constexpr (NEE) {  // contrib already holds the light samples of the earlier vertices
+                if (missed) {
+                    const float4 c = ps.contrib[slot];
+                    ps.contrib[slot] = make_float4(c.x + beta.x * l.x, c.y + beta.y * l.y, c.z + beta.z * l.z, 0.0f);
+                }
+            } else {
+                ps.contrib[slot] = make_float4(beta.x * l.x, beta.y * l.y, beta.z * l.z, 0.0f);
+            }
             return;
         }
     }
@@ -694,10 +700,10 @@ __device__ __forceinline__ void shade_vertex(const DevScene &sc, const DevCamera
 // The queue may mix batches (each at a different bounce): `bp` holds what they have in common (sampling
 // probability, background), the rest comes from the path's region.
 // MODE: 0 = the reference's estimator, 1 = next-event estimation, 2 = the reference's estimator in a scene with
-// participating media.
+// participating media, 3 = next-event estimation in such a scene.
 template <int MT, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, uint32_t q, FreshPaths fp, DevStats *stats) {
-    constexpr bool NEE = MODE == 1, MEDIA = MODE == 2;
+    constexpr bool NEE = MODE == 1 || MODE == 3, MEDIA = MODE == 2 || MODE == 3;
     // a path ends at an emitter (src/camera.rs:288-290), unless a medium scatters it on its way there
     constexpr bool CONTINUES = MT != PTS_MAT_DIFFUSE_LIGHT || MEDIA;
     const WorkList wl = work_list(ps, bounce, fp);
@@ -760,33 +766,35 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DevScene sc, DevCamera cam, Pat
     if constexpr (NEE) wave_push_close(shadows, ps.shadow_queue);
     if ((survivors | shadow_rays) && lane_id() == 0u) {
         atomicAdd(&stats->rays_total, (unsigned long long)(survivors + shadow_rays));
+        if (shadow_rays) atomicAdd(&stats->shadow_rays, (unsigned long long)shadow_rays);
         if (survivors && ps.next_rays) atomicAdd(ps.next_rays, survivors);
         if (survivors && ps.bounce_rays && !NEE && bounce + 1u < BOUNCE_PROFILE_LEN) atomicAdd(&ps.bounce_rays[bounce + 1u], survivors);  // read back to size later launches
     }
 }
 
-// Shadow rays of one step (next-event estimation): closest hit along each, and where that is an
-// emitter, its radiance times the factor the vertex left behind goes to the path.
+// Shadow rays of one step (next-event estimation): each ends just short of the light it is aimed at, and the
+// first hit along it blocks it; an unblocked one adds what its vertex left behind (throughput x BSDF x cosine x
+// emitted radiance over the sum of the two densities) to its path, dimmed by the media it crosses.
 template <bool INSTANCES>
-__global__ __launch_bounds__(BLOCK) void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
+__global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene sc, PathState ps, uint32_t bounce, DevStats *stats) {
     const uint32_t parity = bounce & 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_SHADOW_CHUNKS + parity) * CTL_STRIDE], ps.max_ray_chunks);
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // for the shading of the next step
         ps.ctl[(CTL_SHADOW_CHUNKS + (parity ^ 1u)) * CTL_STRIDE] = 0u;
-        ps.ctl[(CTL_SHADOW_CURSOR + (parity ^ 1u)) * CTL_STRIDE] = 0u;
+        for (uint32_t l = 0; l < WORK_LISTS; l++) ps.ctl[(CTL_SHADOW_WALK_CURSOR + WORK_LISTS * (parity ^ 1u) + l) * CTL_STRIDE] = 0u;
     }
     if (n_chunks == 0u) return;
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     const uint32_t *queue = ps.shadow_queue;
     // a lane's ray is named by its position in the shadow queue
-    walk_world<INSTANCES>(
-        sc, n_chunks * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_SHADOW_CURSOR + parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+    walk_world<INSTANCES, true>(
+        sc, n_chunks * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_SHADOW_WALK_CURSOR + WORK_LISTS * parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &pos, TravRay &r) {
             if (queue[i] == QUEUE_EMPTY) return false;
             pos = i;
             const float4 ro = ps.shadow_o[i], rd = ps.shadow_d[i];
-            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+            r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, rd.w);  // rd.w: where the ray ends
             return true;
         },
         [&](uint32_t pos, f3 &o, f3 &d) {
@@ -794,18 +802,20 @@ __global__ __launch_bounds__(BLOCK) void k_shadow_walk(DevScene sc, PathState ps
             o = mk3(ro.x, ro.y, ro.z);
             d = mk3(rd.x, rd.y, rd.z);
         },
-        [&](bool done, uint32_t pos, const TravRay &r, const HitState &h) {
-            if (!done || h.code == PTD_HIT_MISS) return;
-            const uint32_t type = h.code & 3u;
-            const int32_t mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
-            if (mat < 0 || sc.mats[mat].type != PTS_MAT_DIFFUSE_LIGHT) return;
+        [&](bool done, uint32_t pos, const TravRay &r_in, const HitState &h_in) {
+            if (!done || h_in.code != PTD_HIT_MISS) return;
             const float4 ro = ps.shadow_o[pos], rd = ps.shadow_d[pos];
-            const Surf s = make_surf(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), r.t_max, h.u, h.v, h.prim, h.code);
-            if (!s.front_face) return;
-            const f3 e = tex_value(sc, sc.mats[mat].texture, s.u, s.v, s.p);
             const uint32_t slot = queue[pos];
+            if (sc.n_moving != 0u) {  // the moving spheres, where they are at the path's time
+                TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, rd.w);
+                HitState h = h_in;
+                TravCounters tc{0, 0, 0, 0};
+                hit_moving_spheres(sc, path_time_of_slot(ps, slot), r, h, tc);
+                if (h.code != PTD_HIT_MISS) return;
+            }
             const float4 f = ps.shadow_c[pos], c = ps.contrib[slot];
-            const f3 add = cmul(mk3(f.x, f.y, f.z), e);
+            f3 add = mk3(f.x, f.y, f.z);
+            if (sc.n_media != 0u) add = add * medium_transmittance(sc, mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), rd.w);
             ps.contrib[slot] = make_float4(c.x + add.x, c.y + add.y, c.z + add.z, 0.0f);
         });
 }
@@ -966,7 +976,7 @@ __global__ __launch_bounds__(BLOCK) void k_load_rays(const float *rays, PathStat
         for (uint32_t i = n + threadIdx.x; i < n_chunks * QUEUE_CHUNK; i += BLOCK) ps.ray_queue[0][i] = QUEUE_EMPTY;
         if (threadIdx.x == 0) {
             ps.ctl[(CTL_RAY_CHUNKS + 0) * CTL_STRIDE] = n_chunks;
-            ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE] = 0u;
+            for (uint32_t l = 0; l < WORK_LISTS; l++) ps.ctl[(CTL_WALK_CURSOR + l) * CTL_STRIDE] = 0u;
         }
     }
 }
@@ -1013,7 +1023,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps,
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     walk_world<INSTANCES>(
-        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_RAY_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
+        sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_WALK_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = ps.ray_queue[0][i];
             if (slot == QUEUE_EMPTY) return false;

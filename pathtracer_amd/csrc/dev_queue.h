@@ -54,6 +54,35 @@ __device__ __forceinline__ uint32_t wave_push(WavePush &w, bool want, uint32_t i
     return want ? pos : QUEUE_EMPTY;
 }
 
+// Work handed out as the waves get to it.  Block b of the work is on list b mod WORK_LISTS; a wave draws from the
+// list of its XCD (a counter on a line of its own) and, when that is used up, from the next ones.  All XCDs
+// sweep the work together from its start to its end, whatever the number of workgroups a CU holds at once and
+// whenever they start: what is read and written at any one time lies close together, and results are appended
+// to the queues nearly in the order of the work.  `cursors`: WORK_LISTS control words, CTL_STRIDE apart, zero
+// before the launch.
+struct BlockClaim {
+    uint32_t *cursors;
+    uint32_t n_blocks, list, lists_left;
+    __device__ __forceinline__ void init(uint32_t *c, uint32_t n) {
+        cursors = c;
+        n_blocks = n;
+        list = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % WORK_LISTS;  // HW_REG_XCC_ID[3:0]
+        lists_left = WORK_LISTS;
+    }
+    // the next block for this wave (the same value in every lane); false when the work is used up
+    __device__ __forceinline__ bool next(uint32_t &block) {
+        while (lists_left != 0u) {
+            uint32_t got = 0u;
+            if (lane_id() == 0u) got = atomicAdd(&cursors[list * CTL_STRIDE], 1u);
+            block = (uint32_t)__builtin_amdgcn_readfirstlane((int)got) * WORK_LISTS + list;
+            if (block < n_blocks) return true;
+            lists_left--;
+            list = (list + 1u) % WORK_LISTS;
+        }
+        return false;
+    }
+};
+
 // Identity of the calling wave in the launch, and the number of waves in it.
 __device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u; }
 __device__ __forceinline__ uint32_t wave_count() { return gridDim.x * (blockDim.x / 64u); }

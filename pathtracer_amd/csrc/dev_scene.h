@@ -114,15 +114,17 @@ constexpr uint32_t QUEUE_EMPTY = 0xFFFFFFFFu;
 // the copy the next kernel will fill.
 constexpr uint32_t CTL_STRIDE = 64;  // in 32-bit words
 constexpr uint32_t CTL_RAY_CHUNKS = 0;    // +parity: chunks in ray queue [parity]
-constexpr uint32_t CTL_RAY_CURSOR = 2;    // +parity: 64-entry pieces of ray queue [parity] handed out so far
+constexpr uint32_t CTL_RAY_CURSOR = 2;    // +parity: unused (the ray-drawing kernels take their work from CTL_WALK_CURSOR)
 constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material queue [queue]
 constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
 constexpr uint32_t CTL_SHADOW_CHUNKS = 4 + 2 * MAX_QUEUES;  // +parity: chunks in the shadow-ray queue filled during a step of that parity
-constexpr uint32_t CTL_SHADOW_CURSOR = 6 + 2 * MAX_QUEUES;  // +parity: its pieces handed out so far
+constexpr uint32_t CTL_SHADOW_CURSOR = 6 + 2 * MAX_QUEUES;  // +parity: unused (CTL_SHADOW_WALK_CURSOR)
 constexpr uint32_t WORK_LISTS = 8;  // lists of work blocks, one per XCD: atomics of different XCDs go to different lines
 constexpr uint32_t CTL_PACKET_CURSOR = 8 + 2 * MAX_QUEUES;  // +8*parity+list: blocks of list `list` of the step's new paths handed out so far
 constexpr uint32_t CTL_SHADE_CURSOR = CTL_PACKET_CURSOR + 2 * WORK_LISTS;  // +8*(2*queue+parity)+list: chunk blocks of that list of material queue [queue] handed out
-constexpr uint32_t CTL_WORDS = (8 + 2 * MAX_QUEUES + 2 * WORK_LISTS + 2 * WORK_LISTS * MAX_QUEUES) * CTL_STRIDE;
+constexpr uint32_t CTL_WALK_CURSOR = CTL_SHADE_CURSOR + 2 * WORK_LISTS * MAX_QUEUES;  // +8*parity+list: blocks of that list of ray queue [parity] handed out so far
+constexpr uint32_t CTL_SHADOW_WALK_CURSOR = CTL_WALK_CURSOR + 2 * WORK_LISTS;           // +8*parity+list: the same for the shadow-ray queue
+constexpr uint32_t CTL_WORDS = (8 + 2 * MAX_QUEUES + 2 * WORK_LISTS + 2 * WORK_LISTS * MAX_QUEUES + 4 * WORK_LISTS) * CTL_STRIDE;
 
 // A launch may carry paths of several batches at once (each at a different bounce).  The slot
 // arrays are then cut into regions of region_cap slots, one batch per region, and a path's

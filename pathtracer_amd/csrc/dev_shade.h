@@ -576,6 +576,27 @@ __device__ inline bool medium_event(const DevScene &sc, Rng &rng, f3 o, f3 d, fl
     t_event = best;
     return any;
 }
+// The share of light that gets from o to o + t_end * d without scattering: what a shadow ray of the next-event
+// estimator is dimmed by (the path's own rays scatter instead, medium_event).
+__device__ inline float medium_transmittance(const DevScene &sc, f3 o, f3 d, float t_end) {
+    float tau = 0.0f;
+    for (uint32_t m = 0; m < sc.n_media; m++) {
+        const pts_medium md = sc.media[m];
+        const f3 oc = mk3(md.center[0], md.center[1], md.center[2]) - o;
+        const float a = norm_squared(d);
+        const float h = dot(d, oc);
+        const float c = norm_squared(oc) - md.radius * md.radius;
+        const float disc = h * h - a * c;
+        if (!(disc >= 0.0f)) continue;
+        const float sq = sqrtf(disc);
+        float t1 = (h - sq) / a, t2 = (h + sq) / a;
+        if (t1 < 0.001f) t1 = 0.001f;
+        if (t2 > t_end) t2 = t_end;
+        if (!(t1 < t2)) continue;
+        tau = tau + md.density * ((t2 - t1) * sqrtf(a));
+    }
+    return expf(-tau);
+}
 // Direction of the ray that leaves a scattering event: uniform on the sphere, two draws.
 __device__ inline f3 medium_direction(Rng &rng) {
     const float u1 = rng.range(0.0f, 1.0f), u2 = rng.range(0.0f, 1.0f);
@@ -600,15 +621,24 @@ __device__ inline f3 medium_direction(Rng &rng) {
 // directions (spheres and quads report a solid-angle density).  TRIS_BY_SOLID_ANGLE converts it,
 // distance^2 / (cosine * area) as Quad::pdf does; only the next-event estimator, which is not
 // part of the reference and needs the density Triangle::sample really has, asks for that.
+// Where a ray meets a light of the LightBuffer: distance, surface parameters, the light's index in the scene-wide
+// array of its primitive type, and that type.
+struct LightHit {
+    float t, u, v;
+    uint32_t prim, type;
+};
 template <bool TRIS_BY_SOLID_ANGLE>
-__device__ inline float light_term(const DevScene &sc, uint32_t i, f3 o, f3 d) {
+__device__ inline float light_term(const DevScene &sc, uint32_t i, f3 o, f3 d, LightHit *where = nullptr) {
     const DevSet &L = sc.lights;
-    const uint32_t nt = L.tris.prim_count, ns = L.spheres.prim_count;
+    const uint32_t nt = L.tris.prim_count, ns = L.spheres.prim_count, nq = L.quads.prim_count;
     TravCounters tc{0, 0, 0, 0};
     TravRay r = make_trav_ray(o, d, 0.001f, INFINITY);
     HitState h;
     h.code = PTD_HIT_MISS;
+    h.u = h.v = 0.0f;
+    h.prim = 0u;
     float term = 0.0f;
+    if (i >= nt + ns + nq) return 0.0f;  // an instance in the light list: Hittable::pdf default (src/objects.rs:97-99)
     if (i < nt) {  // Triangle::pdf, tri_mesh.rs:252-261
         const uint32_t g = L.tris.prim_first + i;
         hit_prim<PT_PRIM_TRI>(sc, g, r, h, 0u, tc);
@@ -645,15 +675,26 @@ __device__ inline float light_term(const DevScene &sc, uint32_t i, f3 o, f3 d) {
             term = distance_squared / (cosine * sc.quad_area[g]);
         }
     }
+    if (where) {
+        where->t = r.t_max;
+        where->u = h.u;
+        where->v = h.v;
+        where->prim = h.prim;
+        where->type = h.code & 3u;
+    }
     return term;
 }
+// |a - b| within a ten-thousandth of b (of 1 below that): the same surface point along one ray
+__device__ __forceinline__ bool same_distance(float a, float b) { return fabsf(a - b) <= 1.0e-4f * rmax(1.0f, fabsf(b)); }
 typedef float light_box_t __attribute__((ext_vector_type(8)));  // lower corner, unused, upper corner, unused
 #ifndef PT_LIGHTS_FLAT_MAX
 #define PT_LIGHTS_FLAT_MAX 256u
 #endif
 constexpr uint32_t LIGHTS_FLAT_MAX = PT_LIGHTS_FLAT_MAX;  // more lights of one kind than this: boxes of groups of 32 are tested first
-template <bool TRIS_BY_SOLID_ANGLE = false>
-__device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
+// AT_DISTANCE: only the lights that the ray meets at distance t_at count (next-event estimation: the density with
+// which light sampling yields the very point a BSDF-sampled ray has reached, i.e. the emitter it hit, as a light).
+template <bool TRIS_BY_SOLID_ANGLE = false, bool AT_DISTANCE = false>
+__device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d, float t_at = 0.0f) {
     const DevSet &L = sc.lights;
     // The boxes are read-only for as long as the scene lives and every lane reads the same one: through
     // the constant address space they come in over the scalar unit, one load per box for the wave.
@@ -691,7 +732,13 @@ __device__ inline float light_pdf(const DevScene &sc, f3 o, f3 d) {
             while (maybe != 0) {
                 const uint32_t j = (uint32_t)__ffs((int)maybe) - 1u;
                 maybe &= maybe - 1u;
-                pdf += light_term<TRIS_BY_SOLID_ANGLE>(sc, base + j, o, d);
+                if constexpr (AT_DISTANCE) {
+                    LightHit lh;
+                    const float term = light_term<TRIS_BY_SOLID_ANGLE>(sc, base + j, o, d, &lh);
+                    if (term != 0.0f && same_distance(lh.t, t_at)) pdf += term;
+                } else {
+                    pdf += light_term<TRIS_BY_SOLID_ANGLE>(sc, base + j, o, d);
+                }
             }
         };
         if (n <= LIGHTS_FLAT_MAX) {
@@ -773,11 +820,13 @@ __device__ inline float light_pdf_times_zero(const DevScene &sc, f3 o, f3 d) {
 // OrthonormalBasis::new puts the direction it is given on the second, so its samples point
 // sideways and do not have the density Sphere::pdf reports.  SPHERES_TOWARDS swaps the two
 // components; only the next-event estimator, which is not part of the reference, asks for that.
+// *picked (may be null): the index of the light that was drawn.
 template <bool SPHERES_TOWARDS = false>
-__device__ inline f3 light_sample(const DevScene &sc, Rng &rng, f3 origin) {
+__device__ inline f3 light_sample(const DevScene &sc, Rng &rng, f3 origin, uint32_t *picked = nullptr) {
     const DevSet &L = sc.lights;
     uint32_t i = rng.below(sc.n_light_total);
     const uint32_t nt = L.tris.prim_count, ns = L.spheres.prim_count, nq = L.quads.prim_count;
+    if (picked) *picked = i;
     if (i < nt) {  // Triangle::sample, tri_mesh.rs:263-277
         const uint32_t g = L.tris.prim_first + i;
         const float4 a = sc.tri_hot[3 * g], b = sc.tri_hot[3 * g + 1], c = sc.tri_hot[3 * g + 2];

@@ -123,9 +123,10 @@ constexpr uint32_t WALK_MAX_PASSES = 1u << 20;
 // reload(slot, o, d): the world-frame origin and direction of that ray again (INSTANCES only).
 // sink(done, slot, ray, hit): called by all 64 lanes of the wave together (so it may use
 // ballots), done == true on lanes whose ray has just been finished; ray.t_max is the hit
-// distance.  The work is `n_pieces` pieces of 64 entries; `cursor` counts the pieces
-// handed out.  `bad_refs` is only touched in the bounds-checking build.
-template <bool INSTANCES, class Source, class Reload, class Sink>
+// distance.  The work is `n_pieces` pieces of 64 entries; `cursor`: WORK_LISTS control words,
+// CTL_STRIDE apart, zero before the launch, that count the blocks of pieces handed out.  `bad_refs` is only touched in the bounds-checking build.
+// ANY_HIT: a ray is finished by the first primitive it hits (shadow rays: is there anything in [t_min, t_max]?).
+template <bool INSTANCES, bool ANY_HIT = false, class Source, class Reload, class Sink>
 __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces, uint32_t *cursor, int refill_below, int leaf_batch,
                                            LaneStack &st, unsigned long long *bad_refs, Source &&source, Reload &&reload, Sink &&sink) {
     const DevSet &set = sc.world;
@@ -139,6 +140,11 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
     const uint32_t claim = n_pieces >= 2u * PIECES * wave_count() ? PIECES : 1u;  // pieces per atomic
     // the cursors live in memory every XCD shares: waves that cannot get a piece do not poll them
     if ((uint64_t)wave_index() * claim >= n_pieces) return;
+    // blocks of `claim` pieces, block b on list b mod WORK_LISTS, a wave drawing from the list of its XCD first: one
+    // counter for the whole chip completes an atomic with return every 11 ns whatever the number of waves, which a
+    // launch of a few hundred thousand rays spends a third of its time waiting for
+    BlockClaim blocks;
+    blocks.init(cursor, (n_pieces + claim - 1u) / claim);
     uint32_t res_next = 0u, res_end = 0u;  // claimed entries not dealt yet (same on all lanes)
     bool used_up = false;
     // phase: 0..2 = world buffer being searched, 3 = the world's instance buffer, 4..6 = buffer of
@@ -195,13 +201,12 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
             if (idle == 0ull) break;
             if (res_next == res_end) {
                 if (used_up) break;
-                uint32_t got = 0u;
-                if (lane_id() == 0u) got = atomicAdd(cursor, claim);
-                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                if (got >= n_pieces) {
+                uint32_t block;
+                if (!blocks.next(block)) {
                     used_up = true;
                     break;
                 }
+                const uint32_t got = block * claim;
                 res_next = got * 64u;
                 res_end = (got + claim < n_pieces ? got + claim : n_pieces) * 64u;
             }
@@ -329,6 +334,13 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                             else hit_prim<PT_PRIM_QUAD>(sc, li, r, h, inst_code, tc);
                             li++;
                             if (li == lend) cur = REF_POP;
+                            if (ANY_HIT && h.code != PTD_HIT_MISS) {  // nothing else about this ray matters
+                                phase = PHASE_DONE;
+                                cur = REF_NONE;
+                                li = lend = 0u;
+                                st.sp = 0;
+                                st.has_top = false;
+                            }
                         }
                     }
                 }

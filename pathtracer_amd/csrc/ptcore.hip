@@ -1315,7 +1315,8 @@ struct ShadeLaunch {
 template <int MT>
 static void launch_shade(const ShadeLaunch &l) {
 #define SHADE(N) hipLaunchKernelGGL((k_shade<MT, N>), dim3(l.grid), dim3(BLOCK), 0, l.st, l.ctx->scene, l.ctx->cam, *l.ps, *l.bp, l.bounce, l.q, l.fp, l.ctx->stats)
-    if (l.ps->nee) SHADE(1);
+    if (l.ps->nee && l.ctx->scene.n_media != 0) SHADE(3);
+    else if (l.ps->nee) SHADE(1);
     else if (l.ctx->scene.n_media != 0) SHADE(2);
     else SHADE(0);
 #undef SHADE
@@ -1713,8 +1714,6 @@ static int check_render_args(pt_context *ctx, uint32_t b, uint32_t e) {
     // LightBuffer::sample draws gen_range(0..lights.len()) (src/objects.rs:236-237): rand panics on an empty range
     if (!ctx->nee && ctx->bsdf_prob < 1.0f && ctx->scene.n_light_total == 0)
         return fail(ctx, PT_ERR_INVALID, "BSDF_SAMPLE_PROBABILITY below 1 needs a light to sample, and the scene has none");
-    if (ctx->nee && (ctx->scene.n_media != 0 || ctx->scene.n_moving != 0))
-        return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation does not handle participating media or moving spheres");
     if (ctx->nee && (ctx->counters || !ctx->use_wide()))
         return fail(ctx, PT_ERR_UNSUPPORTED, "next-event estimation runs on the ray-drawing traversal only (no test counters, no reference-order traversal)");
     return PT_OK;
@@ -2168,6 +2167,7 @@ int pt_stats_get(pt_context *ctx, pt_stats *out) {
     out->walk_ms = ctx->walk_ms;
     out->packet_ms = ctx->packet_ms;
     out->walk_launches = ctx->walk_launches;
+    out->shadow_rays = ds.shadow_rays;
     out->packet_launches = ctx->packet_launches;
     out->device_bytes = ctx->device_bytes;
     if (getenv("PT_DEBUG_BOUNCES") && ctx->profiled_batches) {  // per-bounce means of the event timings, for tuning

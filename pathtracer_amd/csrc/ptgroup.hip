@@ -383,6 +383,7 @@ int pt_group_stats_get(pt_group *g, pt_stats *out) {
         out->packet_ms = std::max(out->packet_ms, s.packet_ms);
         out->walk_launches += s.walk_launches;
         out->packet_launches += s.packet_launches;
+        out->shadow_rays += s.shadow_rays;
     }
     return PT_OK;
 }

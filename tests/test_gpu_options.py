@@ -283,8 +283,6 @@ def test_accumulator_identical_however_the_shading_kernels_share_out_their_queue
     from pathtracer_amd.core import PT_OPT_INTEGRATOR, PT_OPT_ROLLING, PT_OPT_SHADE_CLAIM
     src = make(width, 36)
     for integrator in (0, 1):
-        if integrator == 1 and make is scenes.extensions_demo:
-            continue  # next-event estimation refuses media and moving spheres
         ref = None
         for rolling, claim in ((1 << 22, 0), (1 << 22, -1), (1 << 22, 1), (1 << 22, 4), (3 * width * width, 2), (3 * width * width, 64), (0, 0), (0, 3)):
             r = _renderer(src)

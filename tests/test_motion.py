@@ -76,12 +76,29 @@ def test_device_restatement_against_the_oracle_per_sample(which):
 
 
 @pytest.mark.gpu
-def test_modes_that_do_not_handle_moving_spheres_say_so():
-    from pathtracer_amd.core import PT_OPT_INTEGRATOR, HostScene, PtError, Renderer
-    r = Renderer(HostScene(_scene((0, 0, 0), (1, 0, 0), depth=4, spp=4)))
-    r.set_option(PT_OPT_INTEGRATOR, 1)  # next-event estimation keeps the density of the last vertex where the time rides
-    with pytest.raises(PtError):
-        r.render(0, 1, seed=1)
+@pytest.mark.parametrize("which", ["moving", "next_week"])
+def test_next_event_estimation_with_moving_spheres_against_the_oracles_statement(which):
+    """Under next-event estimation the word that carries the path's time holds a density, so the time is taken from
+    the path's generator key where it is needed; shadow rays see the moving spheres where they are at that time."""
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import PT_OPT_INTEGRATOR, PT_OPT_PIPES, PT_OPT_ROLLING, HostScene, Renderer
+    src = (_scene((-1.5, 0.0, 0.0), (1.5, 0.3, 0.5), width=40, spp=36, depth=10, extras=True) if which == "moving"
+           else scenes.next_week_like(40, 36, max_depth=12, extensions=True))
+    o, r = OracleScene(src), Renderer(HostScene(src))
+    r.set_option(PT_OPT_INTEGRATOR, 1)
+    ref = np.nan_to_num(o.render(0, 4, seed=5, iterative=2, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    got = np.nan_to_num(r.render_samples(0, 4, seed=5), nan=0.0, posinf=0.0, neginf=0.0)
+    samples_agree(got, ref, 0.999, which)
+    assert abs(got.sum() - ref.sum()) <= 0.02 * max(ref.sum(), 1e-6)
+    accs = []
+    for pipes, rolling in ((1, 0), (2, 3 * 40 * 40)):
+        r2 = Renderer(HostScene(src))
+        r2.set_option(PT_OPT_INTEGRATOR, 1)
+        r2.set_option(PT_OPT_PIPES, pipes)
+        r2.set_option(PT_OPT_ROLLING, rolling)
+        r2.render(0, 20, seed=7)
+        accs.append(r2.read_accum()[0])
+    assert np.array_equal(accs[0].view(np.uint32), accs[1].view(np.uint32))
 
 
 @pytest.mark.gpu
