@@ -18,8 +18,8 @@ all: pathtracer_amd/libptcore.so pathtracer_amd/libpthost.so pathtracer_amd/ptre
 pathtracer_amd/libptcore.so: $(CORE_SRC) $(CORE_DEP)
 	$(HIPCC) $(HIPFLAGS) -o $@ $(CORE_SRC) -ldl
 
-pathtracer_amd/libpthost.so: pathtracer_amd/host/pthost.cpp pathtracer_amd/host/objload.cpp $(HOST_DEP) pathtracer_amd/libptcore.so
-	$(CXX) $(HOSTFLAGS) -o $@ pathtracer_amd/host/pthost.cpp pathtracer_amd/host/objload.cpp -Lpathtracer_amd -lptcore -Wl,-rpath,'$$ORIGIN'
+pathtracer_amd/libpthost.so: pathtracer_amd/host/pthost.cpp pathtracer_amd/host/objload.cpp pathtracer_amd/host/imgio.cpp $(HOST_DEP) pathtracer_amd/libptcore.so
+	$(CXX) $(HOSTFLAGS) -o $@ pathtracer_amd/host/pthost.cpp pathtracer_amd/host/objload.cpp pathtracer_amd/host/imgio.cpp -Lpathtracer_amd -lptcore -lz -Wl,-rpath,'$$ORIGIN'
 
 pathtracer_amd/ptrender: pathtracer_amd/host/ptrender.cpp $(HOST_DEP) pathtracer_amd/libpthost.so
 	$(CXX) -O2 -ffp-contract=off -std=c++17 -Wall -o $@ -Ipathtracer_amd/host pathtracer_amd/host/ptrender.cpp -Lpathtracer_amd -lpthost -lptcore -Wl,-rpath,'$$ORIGIN'

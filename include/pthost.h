@@ -68,6 +68,17 @@ int pth_obj_mesh_get(const pth_obj *o, uint32_t mesh, pth_obj_mesh *out); /* vie
  * mesh has that attribute; has_normals / has_uvs report which it has. */
 int64_t pth_obj_triangles(const pth_obj *o, uint32_t mesh, float *pos, float *nrm, float *uv, int *has_normals, int *has_uvs);
 
+/* Image files.  Replaces image::open(path)?.to_rgb8() of Image::load (src/textures/image.rs:17-26): a PNG file
+ * (8- or 16-bit grey, grey + alpha, RGB, RGBA or palette, not interlaced) or a PPM file (P6 / P3) as RGB8 texels,
+ * row-major, top row first: the layout pts_texture.texels takes.  Call once with rgb8 = NULL for the size, then
+ * with a buffer of width * height * 3 bytes (capacity = its size).  Returns 0, or 1 with the reason in err; the
+ * reference answers a failed load with its default checker texture, which a pts_texture of type PTS_TEX_IMAGE
+ * with no texels gives. */
+int pth_image_load(const char *path, uint32_t *width, uint32_t *height, uint8_t *rgb8, size_t capacity, char *err, size_t errlen);
+/* Replaces RgbImage::save("strat.png") (src/main.rs:93): an 8-bit RGB PNG of the bytes pth_camera_render or
+ * pt_read_image returned.  Returns 0, or 1 when the file cannot be written. */
+int pth_image_save_png(const char *path, uint32_t width, uint32_t height, const uint8_t *rgb8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,7 +100,7 @@ CORE_SYMBOLS = ["pt_create", "pt_destroy", "pt_last_error", "pt_set_option", "pt
                 "pt_group_upload_scene", "pt_group_set_camera", "pt_group_render", "pt_group_sync", "pt_group_read_accum", "pt_group_read_rgb8",
                 "pt_group_reset_accum", "pt_group_stats_get", "pt_group_stats_reset"]
 HOST_SYMBOLS = ["pth_scene_build", "pth_scene_build_opts", "pth_scene_free", "pth_scene_desc", "pth_camera_desc", "pth_perm", "pth_camera_render",
-                "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles"]
+                "pth_obj_load", "pth_obj_free", "pth_obj_mesh_count", "pth_obj_mesh_get", "pth_obj_triangles", "pth_image_load", "pth_image_save_png"]
 
 
 def core_lib() -> C.CDLL:
@@ -186,6 +186,8 @@ def host_lib() -> C.CDLL:
         L.pth_obj_mesh_get.argtypes = [vp, C.c_uint32, vp]
         L.pth_obj_triangles.argtypes = [vp, C.c_uint32, vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.pth_obj_triangles.restype = C.c_int64
+        L.pth_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), vp, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.pth_image_save_png.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
         _host = L
     return _host
 
@@ -215,6 +217,30 @@ def load_obj(path: str):
         return out
     finally:
         L.pth_obj_free(h)
+
+
+def load_image(path: str) -> np.ndarray:
+    """image::open(path)?.to_rgb8() of Image::load (src/textures/image.rs:17-26) through the host library: a PNG or PPM
+    file as (height, width, 3) uint8, the array SceneSource.image takes.  Raises PtError where the reference would log
+    the failure and fall back to its default texture (SceneSource.image(None) gives that texture)."""
+    L = host_lib()
+    err = C.create_string_buffer(256)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    if L.pth_image_load(os.fsencode(path), C.byref(w), C.byref(h), None, 0, err, len(err)):
+        raise PtError(f"cannot load {err.value.decode()}")
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    if L.pth_image_load(os.fsencode(path), None, None, out.ctypes.data_as(C.c_void_p), out.nbytes, err, len(err)):
+        raise PtError(f"cannot load {err.value.decode()}")
+    return out
+
+
+def save_png(path: str, rgb8: np.ndarray) -> None:
+    """RgbImage::save("*.png") (src/main.rs:93): (height, width, 3) uint8 to an 8-bit RGB PNG file."""
+    a = np.ascontiguousarray(rgb8, np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("expected (height, width, 3) uint8")
+    if host_lib().pth_image_save_png(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data_as(C.c_void_p)):
+        raise PtError(f"cannot write {path}")
 
 
 def _arr(ptr, shape, dtype):

@@ -81,6 +81,9 @@ struct RgbImage {
     RgbImage() = default;
     RgbImage(uint32_t w, uint32_t h) : width(w), height(h), data((size_t)w * h * 3, 0) {}
     bool save_ppm(const std::string &path) const;
+    bool save_png(const std::string &path) const;  // 8-bit RGB, as RgbImage::save("*.png") of src/main.rs:93
+    // PNG or PPM file -> RGB8 as image::open(path)?.to_rgb8() (src/textures/image.rs:18-19); null (and the reason in *why) on failure
+    static std::shared_ptr<const RgbImage> load(const std::string &path, std::string *why = nullptr);
 };
 struct Texture;
 using TextureRef = std::shared_ptr<const Texture>;
@@ -97,7 +100,10 @@ namespace Checkered {
 TextureRef make(TextureRef odd, TextureRef even, float inv_scale);
 TextureRef new_solid(Color odd, Color even, float inv_scale);
 }
-namespace Image { TextureRef make(std::shared_ptr<const RgbImage> image); }
+namespace Image {
+TextureRef make(std::shared_ptr<const RgbImage> image);
+TextureRef load(const std::string &path);  // src/textures/image.rs:17-26; a file that cannot be read gives the default texture
+}
 // Not in the reference: marble-like noise, PTS_TEX_NOISE of ptscene_src.h.
 namespace Noise { TextureRef make(Color color, float scale, uint32_t seed); }
 

@@ -103,7 +103,9 @@ int main(int argc, char **argv) {
                       [](uint32_t done, uint32_t total, void *) { std::fprintf(stderr, "\r%u / %u passes", done, total); }, nullptr);
         auto t2 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "\nRender time: %.3f s\n", std::chrono::duration<double>(t2 - t1).count());
-        if (!image.save_ppm(out)) throw std::runtime_error("cannot write output image");
+        const std::string out_path = out;
+        const bool png = out_path.size() >= 4 && out_path.compare(out_path.size() - 4, 4, ".png") == 0;  // the reference writes PNG (src/main.rs:93)
+        if (!(png ? image.save_png(out) : image.save_ppm(out))) throw std::runtime_error("cannot write output image");
     } catch (const std::exception &e) {
         std::fprintf(stderr, "ptrender: %s\n", e.what());
         return 1;

@@ -267,6 +267,17 @@ class SceneSource:
         self.textures.append((TEX_IMAGE, (0.0, 0.0, 0.0), -1, -1, 0.0, idx))
         return len(self.textures) - 1
 
+    def image_file(self, path: str) -> int:
+        """``Image::load(path)`` (src/textures/image.rs:17-26): the file's texels, or the default texture (and the
+        reference's log line) when the file cannot be read."""
+        from .core import PtError, load_image
+        try:
+            return self.image(load_image(path))
+        except PtError as e:
+            import sys
+            print(f"Failed to load image: '{path}'... Using default texture instead... ({e})", file=sys.stderr)
+            return self.image(None)
+
     # -- materials (src/materials/*.rs) ---------------------------------------
     def _mat(self, type_, tex, params) -> int:
         p = [0.0] * 14
