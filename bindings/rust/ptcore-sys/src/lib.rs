@@ -99,7 +99,10 @@ pub struct pt_instance_desc {
     pub transform: [f32; 16],
     pub inverse: [f32; 16],
     pub child_set: u32,
-    pub reserved: [u32; 3],
+    /// Levels of an instance that was nested, outer to inner: records `chain_first .. chain_first + chain_count`.
+    pub chain_first: u32,
+    pub chain_count: u32,
+    pub reserved: u32,
 }
 
 /// One `Arc<dyn Material>`.

@@ -159,7 +159,7 @@ impl FlatScene {
             let first = self.instances.len();
             // reserve the records first so that the instance BVH's offsets stay valid, then fill the children in
             for _ in &p.instances.buffer {
-                self.instances.push(pt_instance_desc { transform: [0.0; 16], inverse: [0.0; 16], child_set: 0, reserved: [0; 3] });
+                self.instances.push(pt_instance_desc { transform: [0.0; 16], inverse: [0.0; 16], child_set: 0, chain_first: 0, chain_count: 0, reserved: 0 });
             }
             for (k, inst) in p.instances.buffer.iter().enumerate() {
                 let child = self.add_set(&inst.obj, false);

@@ -73,7 +73,15 @@ typedef struct pt_instance_desc {
     float transform[16];
     float inverse[16];
     uint32_t child_set; /* index into sets[]; the child may not contain instances */
-    uint32_t reserved[3];
+    /* An instance that sat inside another instance's set (src/objects.rs:281-286: an Instance holds a whole
+     * PrimitiveBuffer, instances included) is listed in the world's set with the OUTERMOST instance's matrices in
+     * this record, child_set = the set of the innermost one, and the levels further in as chain_count records
+     * instances[chain_first ..], outer to inner, which belong to no set and have no chain of their own.  Rays go
+     * through the inverses in that order and hits come back through the transforms in the opposite order, one
+     * level at a time as the reference's nested Instance::hit does (:385-397), so the numbers match it bit for bit.
+     * 0 / 0 for an instance that was not nested. */
+    uint32_t chain_first, chain_count;
+    uint32_t reserved;
 } pt_instance_desc;
 
 /* One Arc<dyn Material>. type/texture/p as in pts_material (constructor arguments after

@@ -42,7 +42,7 @@ class pt_primset_desc(C.Structure):
 
 
 class pt_instance_desc(C.Structure):
-    _fields_ = [("transform", C.c_float * 16), ("inverse", C.c_float * 16), ("child_set", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+    _fields_ = [("transform", C.c_float * 16), ("inverse", C.c_float * 16), ("child_set", C.c_uint32), ("chain_first", C.c_uint32), ("chain_count", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class pt_material_desc(C.Structure):

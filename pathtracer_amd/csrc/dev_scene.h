@@ -6,7 +6,7 @@
 //   tri_cold   6 x float4 per triangle (96 B): the 8x3 attribute matrix, fetched once per path vertex
 //   spheres    1 x float4 (center, radius)
 //   quads      4 x float4 (64 B): (origin, u.x) (u.yz, v.xy) (v.z, normal) (w, d)
-//   insts      7 x float4 (112 B): inverse 3x4, transform 3x4, (child_set, -, -, -)
+//   insts      7 x float4 (112 B): inverse 3x4, transform 3x4, (child_set, chain_first, chain_count, -)
 // Primitive indices stored in hit records are scene-wide ("global") indices into these arrays.
 #pragma once
 #include <hip/hip_runtime.h>

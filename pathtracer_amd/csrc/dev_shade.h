@@ -113,12 +113,15 @@ __device__ inline Surf make_surf(const DevScene &sc, f3 ro, f3 rd, float t, floa
     Surf s;
     const uint32_t type = code & 3u, inst1 = code >> 2;
     Affine fwd;
+    float4 inst_last = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (inst1) {
         const float4 *ip = sc.insts + 7 * (size_t)(sc.world.insts.prim_first + inst1 - 1u);
         const Affine inv = load_affine(ip);
         fwd = load_affine(ip + 3);
+        inst_last = ip[6];
         ro = xf_point(inv, ro);
         rd = xf_vector(inv, rd);
+        chain_into(sc, inst_last, ro, rd);
     }
     f3 outward;
     if (type == PT_PRIM_TRI) {
@@ -158,6 +161,7 @@ __device__ inline Surf make_surf(const DevScene &sc, f3 ro, f3 rd, float t, floa
     s.front_face = dot(rd, outward) < 0.0f;  // set_face_normal, src/objects.rs:82-90
     s.normal = s.front_face ? outward : -outward;
     if (inst1) {
+        chain_out_of(sc, inst_last, s.p, s.normal);
         s.p = xf_point(fwd, s.p);
         s.normal = xf_vector(fwd, s.normal);
     }

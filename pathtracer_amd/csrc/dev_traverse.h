@@ -389,14 +389,41 @@ __device__ __forceinline__ Affine load_affine(const float4 *p) {
     return a;
 }
 
+// An instance that sat inside another instance's set is searched from the top level (the host layer lifts it
+// there), but keeps the steps of its nesting so that every number comes out as the reference's level-by-level
+// Instance::hit computes it (src/objects.rs:385-397): its own record is the outermost instance, records
+// chain_first .. chain_first + chain_count - 1 of the instance array (which belong to no set) are the ones further
+// in, outer to inner.  `last` is the record's seventh float4: (child set, chain_first, chain_count, -).
+__device__ __forceinline__ void chain_into(const DevScene &sc, float4 last, f3 &o, f3 &d) {
+    const uint32_t n = __float_as_uint(last.z);
+    const float4 *cp = sc.insts + 7 * (size_t)__float_as_uint(last.y);
+    for (uint32_t k = 0; k < n; k++, cp += 7) {
+        const Affine inv = load_affine(cp);
+        o = xf_point(inv, o);
+        d = xf_vector(inv, d);
+    }
+}
+// ... and the way back for the hit point and the normal: the innermost `transform` first (:393-394 at each level)
+__device__ __forceinline__ void chain_out_of(const DevScene &sc, float4 last, f3 &p, f3 &n) {
+    const float4 *cp = sc.insts + 7 * (size_t)__float_as_uint(last.y);
+    for (uint32_t k = __float_as_uint(last.z); k-- > 0u;) {
+        const Affine fwd = load_affine(cp + 7 * (size_t)k + 3);
+        p = xf_point(fwd, p);
+        n = xf_vector(fwd, n);
+    }
+}
+
 // Instance::hit: the ray is taken into the instance's frame without renormalising the
 // direction, so t is shared between the two frames.
 __device__ __forceinline__ void hit_instance(const DevScene &sc, uint32_t gi, TravRay &r, HitState &h, LaneStack &st,
                                              TravCounters &tc) {
     const float4 *ip = sc.insts + 7 * (size_t)gi;
     const Affine inv = load_affine(ip);
-    const uint32_t child = __float_as_uint(ip[6].x);
-    TravRay local = make_trav_ray(xf_point(inv, r.o), xf_vector(inv, r.d), r.t_min, r.t_max);
+    const float4 last = ip[6];
+    const uint32_t child = __float_as_uint(last.x);
+    f3 lo = xf_point(inv, r.o), ld = xf_vector(inv, r.d);
+    chain_into(sc, last, lo, ld);
+    TravRay local = make_trav_ray(lo, ld, r.t_min, r.t_max);
     HitState hl;
     hl.code = PTD_HIT_MISS;
     hl.u = hl.v = 0.0f;

@@ -315,12 +315,16 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                             const uint32_t gi = li++;
                             const float4 *ip = sc.insts + 7 * (size_t)gi;
                             const Affine inv = load_affine(ip);
-                            child = __float_as_uint(ip[6].x);
+                            const float4 last = ip[6];
+                            child = __float_as_uint(last.x);
                             WALK_CHECK(child < sc.n_sets, 3)
+                            WALK_CHECK((uint64_t)__float_as_uint(last.y) + __float_as_uint(last.z) <= sc.n_insts, 3)
                             st.push(cur, __uint_as_float(li));  // where to go on in the instance buffer
                             st.push(REF_RETURN, 0.0f);
                             const float t_min = r.t_min, t_max = r.t_max;
-                            r = make_trav_ray(xf_point(inv, r.o), xf_vector(inv, r.d), t_min, t_max);
+                            f3 lo = xf_point(inv, r.o), ld = xf_vector(inv, r.d);
+                            chain_into(sc, last, lo, ld);  // an instance that was nested: the levels further in
+                            r = make_trav_ray(lo, ld, t_min, t_max);
                             lane_plain = ray_is_plain(r);
                             inst_code = (gi - set.insts.prim_first + 1u) << 2;
                             phase = PHASE_CHILD;

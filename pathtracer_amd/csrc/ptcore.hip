@@ -761,11 +761,14 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
             if (bufs[t]->node_count && !nodes_ok(s->nodes + bufs[t]->node_first, bufs[t]->node_count, bufs[t]->prim_count, why))
                 return fail(ctx, PT_ERR_INVALID, "set %u buffer %d: %s", k, t, why.c_str());
         if (k >= 1 && ps.instances.prim_count && k != 1)
-            return fail(ctx, PT_ERR_UNSUPPORTED, "set %u: instances inside an instance: lift them to the top level with composed transforms first (libpthost does)", k);
+            return fail(ctx, PT_ERR_UNSUPPORTED, "set %u: instances inside an instance: list them in the world's set with their levels as chain records (libpthost does)", k);
     }
     for (uint32_t i = 0; i < s->n_instances; i++) {
         const pt_instance_desc &in = s->instances[i];
         if (in.child_set < 2 || in.child_set >= s->n_sets) return fail(ctx, PT_ERR_INVALID, "instance %u: child_set out of range", i);
+        if ((uint64_t)in.chain_first + in.chain_count > s->n_instances) return fail(ctx, PT_ERR_INVALID, "instance %u: chain records out of range", i);
+        for (uint32_t k = 0; k < in.chain_count; k++)
+            if (s->instances[in.chain_first + k].chain_count != 0) return fail(ctx, PT_ERR_INVALID, "instance %u: a chain record has a chain of its own", i);
         const float *r3t = in.transform + 12, *r3i = in.inverse + 12;
         if (r3t[0] != 0.0f || r3t[1] != 0.0f || r3t[2] != 0.0f || r3t[3] != 1.0f || r3i[0] != 0.0f || r3i[1] != 0.0f || r3i[2] != 0.0f || r3i[3] != 1.0f)
             return fail(ctx, PT_ERR_UNSUPPORTED, "instance %u: matrix is not affine", i);
@@ -848,7 +851,9 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         std::memcpy(o + 12, s->instances[i].transform, 12 * sizeof(float));
         uint32_t cs = s->instances[i].child_set;
         std::memcpy(o + 24, &cs, 4);
-        o[25] = o[26] = o[27] = 0.0f;
+        std::memcpy(o + 25, &s->instances[i].chain_first, 4);
+        std::memcpy(o + 26, &s->instances[i].chain_count, 4);
+        o[27] = 0.0f;
     }
     static_assert(sizeof(pt_node) == 32, "pt_node must be 32 bytes");
     if (s->n_nodes) std::memcpy(nodes.data(), s->nodes, (size_t)s->n_nodes * 32);
@@ -951,6 +956,8 @@ int pt_upload_scene(pt_context *ctx, const pt_scene_desc *s) {
         const DevSet &w = sets[0];
         ctx->packet_ok = true;  // every set a ray can get into has reference-order nodes (or no tree at all)
         for (const DevSet &ds : sets) ctx->packet_ok = ctx->packet_ok && ds.tris.tree != 2u && ds.spheres.tree != 2u && ds.quads.tree != 2u && ds.insts.tree != 2u;
+        // ... and it enters an instance in one step: the levels of an instance that was nested are the per-lane kernel's
+        for (uint32_t i = 0; i < s->n_instances; i++) ctx->packet_ok = ctx->packet_ok && s->instances[i].chain_count == 0;
         (void)w;
     }
     if ((rc = dev_upload(ctx, ctx->scene_allocs, &pi, s->quad_mat, s->n_quads))) return rc;

@@ -394,7 +394,11 @@ void Instance::scale_x(float x) { transform = Matrix4::new_nonuniform_scaling(Ve
 void Instance::scale_y(float y) { transform = Matrix4::new_nonuniform_scaling(Vector3(1, y, 1)) * transform; inverse = inverse * Matrix4::new_nonuniform_scaling(Vector3(1, 1.0f / y, 1)); }
 void Instance::scale_z(float z) { transform = Matrix4::new_nonuniform_scaling(Vector3(1, 1, z)) * transform; inverse = inverse * Matrix4::new_nonuniform_scaling(Vector3(1, 1, 1.0f / z)); }
 void Instance::scale_uniform(float s) { transform = Matrix4::new_scaling(s) * transform; inverse = inverse * Matrix4::new_scaling(1.0f / s); }
-BBox Instance::bbox() const { return obj->bbox.transform(transform); }
+BBox Instance::bbox() const {  // src/objects.rs:407-409, level by level for an instance that was nested
+    BBox b = obj->bbox;
+    for (auto it = inner_levels.rbegin(); it != inner_levels.rend(); ++it) b = b.transform(it->first);
+    return b.transform(transform);
+}
 
 void PrimitiveBuffer::add_triangle(Triangle t) { bbox = bbox.merge(t.bbox()); triangles.push(std::move(t)); }
 void PrimitiveBuffer::add_sphere(Sphere s) { bbox = bbox.merge(s.bbox()); spheres.push(std::move(s)); }
@@ -741,6 +745,14 @@ uint32_t FlatScene::add_set(const PrimitiveBuffer &pb, const InnerPrimitiveBuffe
         std::memcpy(id.transform, in.transform.m, sizeof id.transform);
         std::memcpy(id.inverse, in.inverse.m, sizeof id.inverse);
         id.child_set = 0u;  // patched by build() once the child set has an index
+        id.chain_first = (uint32_t)chain_.size();  // within chain_; build() moves the records behind every set's instances
+        id.chain_count = (uint32_t)in.inner_levels.size();
+        for (const auto &level : in.inner_levels) {
+            pt_instance_desc step{};
+            std::memcpy(step.transform, level.first.m, sizeof step.transform);
+            std::memcpy(step.inverse, level.second.m, sizeof step.inverse);
+            chain_.push_back(step);
+        }
         instances_[inst_first + k] = id;
     }
     return index;
@@ -766,24 +778,27 @@ void FlatScene::add_moving_sphere(Point3 center0, Point3 center1, float radius, 
 }
 
 // An Instance holds a whole PrimitiveBuffer (src/objects.rs:281-286), which may hold instances again.  The device
-// library searches two levels, so instances inside instances are lifted to the top level with their transforms
-// composed: Instance::hit of the outer one takes the ray through `inverse`, the inner one through its own
-// (src/objects.rs:385-390), and the way back goes through the two `transform`s in the opposite order (:393-394),
-// so the lifted instance carries transform = outer * inner and inverse = inner^-1 * outer^-1.  Results equal the
-// nested evaluation up to the rounding of the matrix products; which of several hits at exactly the same
-// distance wins may differ, because the lifted instances are visited in the order of their own place in the top
+// library searches two levels, so an instance inside an instance is listed at the top level, once for every way
+// down to it, and keeps the levels of its nesting: Instance::hit of the outermost one takes the ray through its
+// `inverse`, the next one through its own, and so on (src/objects.rs:385-390), and the way back goes through the
+// `transform`s in the opposite order (:393-394).  The device applies them one at a time in that order, so distances,
+// hit points and normals are the nested evaluation's to the bit.  What may differ: which of several hits at exactly
+// the same distance wins, because the lifted instances are visited in the order of their own place in the top
 // level's instance buffer (and its BVH, rebuilt over the longer list) rather than inside the outer instance.
-static void lift_instances(const Instance &in, const Matrix4 &transform, const Matrix4 &inverse, int depth, InnerPrimitiveBuffer<Instance> &out) {
-    if (depth > 8) throw std::runtime_error("instance nesting too deep");
+static void lift_instances(const Instance &in, std::vector<std::pair<Matrix4, Matrix4>> &levels, InnerPrimitiveBuffer<Instance> &out) {
+    if (levels.size() > 8) throw std::runtime_error("instance nesting too deep");
+    levels.emplace_back(in.transform, in.inverse);
     const PrimitiveBuffer &child = *in.obj;
     if (child.triangles.len() + child.spheres.len() + child.quads.len() > 0 || child.instances.len() == 0) {
         Instance flat;
         flat.obj = in.obj;  // described without its instance buffer
-        flat.transform = transform;
-        flat.inverse = inverse;
+        flat.transform = levels[0].first;
+        flat.inverse = levels[0].second;
+        flat.inner_levels.assign(levels.begin() + 1, levels.end());
         out.push(std::move(flat));
     }
-    for (const Instance &inner : child.instances.buffer) lift_instances(inner, transform * inner.transform, inner.inverse * inverse, depth + 1, out);
+    for (const Instance &inner : child.instances.buffer) lift_instances(inner, levels, out);
+    levels.pop_back();
 }
 
 void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights) {
@@ -791,7 +806,8 @@ void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights)
     for (const Instance &in : objects.instances.buffer) nested = nested || in.obj->instances.len() > 0;
     InnerPrimitiveBuffer<Instance> lifted;
     if (nested) {
-        for (const Instance &in : objects.instances.buffer) lift_instances(in, in.transform, in.inverse, 0, lifted);
+        std::vector<std::pair<Matrix4, Matrix4>> levels;
+        for (const Instance &in : objects.instances.buffer) lift_instances(in, levels, lifted);
         if (!objects.instances.bvh.empty() && !BVHBuilder::build(lifted)) throw std::runtime_error("BVHBuilder::build failed: tree deeper than 63 levels");
     }
     const InnerPrimitiveBuffer<Instance> &top = nested ? lifted : objects.instances;
@@ -809,6 +825,15 @@ void FlatScene::build(const PrimitiveBuffer &objects, const LightBuffer &lights)
         const uint32_t child = add_set(*lights.objects.instances.buffer[k].obj, nullptr);
         instances_[li.prim_first + k].child_set = child;
     }
+    // the levels of nested instances go behind every set's instances
+    const uint32_t chain_base = (uint32_t)instances_.size();
+    for (uint32_t k = 0; k < wi.prim_count; k++) {
+        pt_instance_desc &id = instances_[wi.prim_first + k];
+        for (uint32_t j = 0; j < id.chain_count; j++) chain_[id.chain_first + j].child_set = id.child_set;
+        id.chain_first = id.chain_count ? id.chain_first + chain_base : 0u;
+    }
+    for (uint32_t k = 0; k < li.prim_count; k++) instances_[li.prim_first + k].chain_first = instances_[li.prim_first + k].chain_count = 0u;
+    instances_.insert(instances_.end(), chain_.begin(), chain_.end());
     // moving spheres go behind the spheres of the sets, as they are at time 0
     for (const pts_moving_sphere &m : moving_) {
         spheres_.insert(spheres_.end(), {m.center0[0], m.center0[1], m.center0[2], m.radius});

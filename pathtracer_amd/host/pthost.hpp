@@ -197,6 +197,9 @@ struct Quad {  // src/objects/quad_mesh.rs:10-102
 struct Instance {  // src/objects.rs:281-381
     std::shared_ptr<const PrimitiveBuffer> obj;
     Matrix4 transform, inverse;
+    // Set by the scene flattening only, for an instance that sat inside other instances: `transform` / `inverse`
+    // above are then the outermost level's, and these are the (transform, inverse) of the levels further in, outer to inner.
+    std::vector<std::pair<Matrix4, Matrix4>> inner_levels;
     static Instance from_obj(PrimitiveBuffer obj);
     void rotate(float angle, Vector3 axis);
     void rotate_x(float angle);
@@ -283,7 +286,7 @@ private:
     pt_buffer_desc add_nodes(const InnerPrimitiveBuffer<T> &b, uint32_t prim_first);
     std::vector<float> tri_data_, spheres_, quads_;
     std::vector<int32_t> tri_mat_, sphere_mat_, quad_mat_;
-    std::vector<pt_instance_desc> instances_;
+    std::vector<pt_instance_desc> instances_, chain_;
     std::vector<pt_node> nodes_;
     std::vector<pt_primset_desc> sets_;
     std::vector<pt_material_desc> materials_;

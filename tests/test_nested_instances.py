@@ -1,11 +1,13 @@
 """Instances inside instances (src/objects.rs:281-286: an Instance holds a whole PrimitiveBuffer, which has an
-instance buffer of its own).  The device library searches two levels; the host layer lifts deeper instances to the
-top level with composed transforms.  The oracle evaluates the nesting as the reference does, level by level."""
+instance buffer of its own).  The device library searches two levels; the host layer lists deeper instances at the
+top level and keeps the levels of their nesting as chain records, which the device applies one after the other.
+The oracle evaluates the nesting as the reference does, level by level."""
 import numpy as np
 import pytest
 
 from pathtracer_amd.core import HostScene
 from pathtracer_amd.scene_src import CameraSrc, InstanceSrc, PrimSet, SceneSource, new_box
+from tests.util import samples_agree
 
 
 def nested_scene(width=48, spp=16, top_bvh=True) -> SceneSource:
@@ -43,21 +45,31 @@ def nested_scene(width=48, spp=16, top_bvh=True) -> SceneSource:
     return s
 
 
-def test_host_layer_lifts_nested_instances_with_composed_transforms():
+def test_host_layer_lifts_nested_instances_and_keeps_their_levels():
     from oracle.pyoracle import OracleScene
     src = nested_scene()
     h = HostScene(src)
     # 2 slabs x (slab itself + 2 posts x (post itself + 2 bead strings)) + (only_nested: just its bead string) + 1 box
-    assert h.desc.n_instances == 2 * (1 + 2 * 3) + 1 + 1
     world = h.set_desc(0)
-    assert world.instances.prim_count == h.desc.n_instances and world.instances.node_count > 0
+    n_top = 2 * (1 + 2 * 3) + 1 + 1
+    assert world.instances.prim_count == n_top and world.instances.node_count > 0
     for k in range(2, h.desc.n_sets):
         assert h.set_desc(k).instances.prim_count == 0  # no set below the top level holds instances
-    inst = h.instances(world.instances)
-    for row in inst:  # transform and inverse stay inverses of each other, and affine
-        t, i = row[:16].reshape(4, 4).astype(np.float64), row[16:].reshape(4, 4).astype(np.float64)
+    # levels further in: one per post (below a slab), two per bead string below a post, one for the string of only_nested
+    depth = sorted(h.desc.instances[world.instances.prim_first + k].chain_count for k in range(n_top))
+    assert depth == [0] * 3 + [1] * 5 + [2] * 8
+    assert h.desc.n_instances == n_top + sum(depth)
+    for k in range(n_top):
+        rec = h.desc.instances[world.instances.prim_first + k]
+        assert rec.chain_count == 0 or rec.chain_first >= n_top  # chain records belong to no set
+        for j in range(rec.chain_count):
+            step = h.desc.instances[rec.chain_first + j]
+            assert step.chain_count == 0 and step.child_set == rec.child_set
+    for k in range(h.desc.n_instances):  # transform and inverse are inverses of each other at every level, and affine
+        rec = h.desc.instances[k]
+        t, i = np.array(rec.transform[:], np.float64).reshape(4, 4), np.array(rec.inverse[:], np.float64).reshape(4, 4)
         assert np.allclose(t @ i, np.eye(4), atol=2e-5)
-        assert np.array_equal(row[12:16], [0, 0, 0, 1]) and np.array_equal(row[28:32], [0, 0, 0, 1])
+        assert np.array_equal(t[3], [0, 0, 0, 1]) and np.array_equal(i[3], [0, 0, 0, 1])
     # a scene without nesting is described exactly as before: same instances in the builder's order as the oracle's
     from pathtracer_amd import scenes
     plain = scenes.cornell(32, 4)
@@ -82,20 +94,19 @@ def test_nested_instances_first_hits_and_radiance_against_the_oracle(top_bvh):
     h = r.trace(rays)
     nested_hits = (ids[:, 2] >= 0).sum()
     assert nested_hits > 3000
-    # the composed matrices round differently from two successive transforms: distances agree to a few ulps of the
-    # scene's scale, and a ray may pick the other of two surfaces that lie within that of each other
-    hit_o, hit_d = ids[:, 0] >= 0, h["prim_type"] >= 0
-    assert (hit_o != hit_d).mean() < 2e-4
-    both = hit_o & hit_d
-    close = np.abs(h["t"][both] - tuv[both, 0]) <= 2e-5 * np.maximum(1.0, np.abs(tuv[both, 0]))
-    assert close.mean() > 0.998, close.mean()  # grazing rays may pick the other of two nearby surfaces
-    assert (h["prim_type"][both] != ids[both, 0]).mean() < 5e-4
-    # rays that meet no instance at all are untouched by the lifting: bit-identical
-    plain = both & (ids[:, 2] < 0) & (h["inst_id"] < 0)
-    assert plain.sum() > 1000 and np.array_equal(h["t"][plain].view(np.uint32), tuv[plain, 0].view(np.uint32))
+    # the device takes the ray through the levels one at a time as the reference's nested Instance::hit does, so the
+    # distance of every hit is the oracle's to the bit; the instance numbering differs (the oracle numbers the top
+    # level's instances, the device the lifted list), so ids are compared through type and distance.  Two hits at
+    # exactly the same distance in two different lifted instances (a post stands on its slab: the two faces coincide)
+    # may be resolved the other way round, which shows in (u, v) only: a handful of the rays.
+    assert np.array_equal(h["prim_type"], ids[:, 0])
+    assert np.array_equal(h["t"].view(np.uint32), tuv[:, 0].view(np.uint32))
+    m = ids[:, 0] >= 0
+    other = m & ((h["u"].view(np.uint32) != tuv[:, 1].view(np.uint32)) | (h["v"].view(np.uint32) != tuv[:, 2].view(np.uint32)))
+    assert other.sum() <= 4 and (ids[other, 0] == 2).all() and (ids[other, 2] >= 0).all(), (int(other.sum()), ids[other])
+    assert np.array_equal(h["inst_id"] >= 0, ids[:, 2] >= 0)
     got = np.nan_to_num(r.render_samples(0, 16, seed=8), nan=0.0, posinf=0.0, neginf=0.0)
     want = np.nan_to_num(o.render(0, 16, seed=8, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
-    agree = np.all(np.abs(got - want) <= 1e-3 * np.maximum(1.0, np.abs(want)), axis=-1)
-    assert agree.mean() > 0.98, agree.mean()
+    samples_agree(got, want, 0.999, f"nested top_bvh={top_bvh}")
     assert abs(got.mean() - want.mean()) < 0.02 * want.mean()
     r.close()
