@@ -244,9 +244,10 @@ __global__ __launch_bounds__(BB) void k_emit(uint32_t n, Links L, const float4 *
     }
     const int l = (box[0][axis] + box[0][3 + axis]) <= (box[1][axis] + box[1][3 + axis]) ? 0 : 1, r = l ^ 1;
     float4 *w = wide + 4 * (size_t)i;
-    w[0] = make_float4(box[l][0], box[l][1], box[l][2], box[l][3]);
-    w[1] = make_float4(box[l][4], box[l][5], box[r][0], box[r][1]);
-    w[2] = make_float4(box[r][2], box[r][3], box[r][4], box[r][5]);
+    // the layout of a 64-byte node's two boxes (dev_traverse.h): x and y of a corner side by side, the z of both corners side by side
+    w[0] = make_float4(box[l][0], box[l][1], box[l][3], box[l][4]);
+    w[1] = make_float4(box[l][2], box[l][5], box[r][2], box[r][5]);
+    w[2] = make_float4(box[r][0], box[r][1], box[r][3], box[r][4]);
     w[3] = make_float4(__uint_as_float(ref[l]), __uint_as_float(ref[r]), __uint_as_float(axis), 0.0f);
 }
 

@@ -173,6 +173,13 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
             lend = li + count;
         }
     };
+    // the same for a reference out of a node or off the stack, which is never REF_LINEAR
+    auto open_leaf_ref = [&]() {
+        if ((cur & WIDE_LEAF) && cur < REF_POP) {
+            li = prim_base + (cur & 0xFFFFFFu);
+            lend = li + ((cur >> 24) & 0x7Fu);
+        }
+    };
     // Starts the search of one buffer.  Inside an instance an empty or missed buffer means what a
     // pop down to the instance's stack bottom means.
     auto begin_buffer = [&](const DevBuffer &buf) {
@@ -278,27 +285,24 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                 float el, er;
                 bool hl, hr;
                 if (plain) {
-                    hl = slab_test_entry_plain(a.x, a.y, a.z, a.w, b.x, b.y, r, el);
-                    hr = slab_test_entry_plain(b.z, b.w, c.x, c.y, c.z, c.w, r, er);
+                    slab_test_two_plain(a, b, c, r, hl, el, hr, er);
                 } else {
-                    hl = slab_test_entry(a.x, a.y, a.z, a.w, b.x, b.y, r, el);
-                    hr = slab_test_entry(b.z, b.w, c.x, c.y, c.z, c.w, r, er);
+                    hl = slab_test_entry(a.x, a.y, b.x, a.z, a.w, b.y, r, el);
+                    hr = slab_test_entry(c.x, c.y, b.z, c.z, c.w, b.w, r, er);
                 }
                 const uint32_t lref = __float_as_uint(d.x), rref = __float_as_uint(d.y), axis = __float_as_uint(d.z);
-                const float da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
-                const bool neg = da < 0.0f;
-                const uint32_t near_ref = neg ? rref : lref, far_ref = neg ? lref : rref;
-                const bool hn = neg ? hr : hl, hf = neg ? hl : hr;
-                const float ef = neg ? el : er;
-                if (hn) {
-                    if (hf) st.push(far_ref, ef);
-                    cur = near_ref;
-                } else if (hf) {
-                    cur = far_ref;
-                } else {
-                    cur = REF_POP;
+                // one child passed: that one; none: the stack; both: the near one, which the ray's direction along the
+                // node's axis decides (src/bvh.rs:757-771), with the far one stacked.  Written so that the ray's sign is
+                // only looked at where both passed: selecting between the two outcomes per lane costs vector instructions.
+                cur = hl ? lref : rref;
+                if (!(hl || hr)) cur = REF_POP;
+                if (hl && hr) {
+                    const float da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
+                    const bool neg = da < 0.0f;
+                    st.push(neg ? lref : rref, neg ? el : er);
+                    cur = neg ? rref : lref;
                 }
-                open_leaf(0u);  // a reference out of a node or off the stack is never REF_LINEAR
+                open_leaf_ref();
             }
             // (B) one primitive of a pending leaf, once enough lanes have one or no lane has a node left
             {
@@ -352,7 +356,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
             // (P) the one place where the stack is popped
             if (cur == REF_POP) {
                 cur = walk_pop(st, r);
-                open_leaf(0u);
+                open_leaf_ref();
             }
             // (C) nothing left in this buffer: on to the next one, or out of the instance
             if (INSTANCES && cur == REF_RETURN) {

@@ -674,6 +674,12 @@ struct WideBuild {
     uint32_t wide_first, root_ref, depth;
     float rmin[3], rmax[3];
 };
+// The two boxes of a 64-byte node (dev_traverse.h, wide_box_l / wide_box_r read them back).
+static void wide_boxes(float4 *w, const float *lmin, const float *lmax, const float *rmin, const float *rmax) {
+    w[0] = make_float4(lmin[0], lmin[1], lmax[0], lmax[1]);
+    w[1] = make_float4(lmin[2], lmax[2], rmin[2], rmax[2]);
+    w[2] = make_float4(rmin[0], rmin[1], rmax[0], rmax[1]);
+}
 static bool build_wide(const pt_node *nodes, uint32_t count, std::vector<float4> &wide, WideBuild &out) {
     out.wide_first = (uint32_t)(wide.size() / 4);
     std::memcpy(out.rmin, nodes[0].bmin, 12);
@@ -727,9 +733,7 @@ static bool build_wide(const pt_node *nodes, uint32_t count, std::vector<float4>
         if (L.b & PT_NODE_LEAF) { if (!leaf_ref(L, lref)) return false; } else lref = wide_index[i + 1];
         if (R.b & PT_NODE_LEAF) { if (!leaf_ref(R, rref)) return false; } else rref = wide_index[nodes[i].a];
         float4 *w = &wide[base + 4 * k];
-        w[0] = make_float4(L.bmin[0], L.bmin[1], L.bmin[2], L.bmax[0]);
-        w[1] = make_float4(L.bmax[1], L.bmax[2], R.bmin[0], R.bmin[1]);
-        w[2] = make_float4(R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+        wide_boxes(w, L.bmin, L.bmax, R.bmin, R.bmax);
         float fl, fr, fa;
         const uint32_t axis = nodes[i].b;
         std::memcpy(&fl, &lref, 4);
