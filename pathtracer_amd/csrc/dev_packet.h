@@ -49,10 +49,13 @@ template <class LeafFn>
 __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuffer &buf, unsigned long long active, bool plain, TravRay &r, int floor,
                                                 LeafFn &&leaf) {
     if (buf.prim_count == 0u || active == 0ull) return;
-    const unsigned long long lane_bit = 1ull << lane_id();
+    // Lane masks stay in scalar registers: which lanes a mask names is read back as a condition
+    // (inverse ballot: the mask itself becomes the select / branch condition, no vector instruction), and masks are
+    // combined with scalar instructions; the kernel is bound by the number of vector instructions it issues.
     if (buf.node_count == 0u) {  // no BVH: src/bvh.rs:726-737
+        const bool on = __builtin_amdgcn_inverse_ballot_w64(active);
 #pragma unroll 1
-        for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i, (active & lane_bit) != 0ull, floor);
+        for (uint32_t i = 0; i < buf.prim_count; i++) leaf(buf.prim_first + i, on, floor);
         return;
     }
     const ScalarF4 nodes = scalar_f4(sc.nodes + 2 * (size_t)buf.node_first);
@@ -62,18 +65,15 @@ __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuf
     unsigned long long mask = active;
     for (;;) {
         const float4 n0 = nodes[2u * cur], n1 = nodes[2u * cur + 1u];
-        bool hit = (mask & lane_bit) != 0ull;
-        if (hit) {
-            float e;
-            hit = plain ? slab_test_entry_plain(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, e) : slab_test(n0, n1, r);
-        }
-        const unsigned long long passed = __ballot(hit);
+        // every lane runs the test, the ones outside `mask` on whatever their registers hold (it reads no memory)
+        float e;
+        const unsigned long long passed = (plain ? __ballot(slab_test_entry_plain(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, e)) : __ballot(slab_test(n0, n1, r))) & mask;
         bool descend = false;
         if (passed != 0ull) {
             const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
             if (!(b & PT_NODE_LEAF)) {
                 const float da = (b == 0u) ? r.d.x : ((b == 1u) ? r.d.y : r.d.z);
-                const unsigned long long right_first = __ballot(hit && da < 0.0f), left_first = passed & ~right_first;
+                const unsigned long long right_first = __ballot(da < 0.0f) & passed, left_first = passed & ~right_first;
                 auto push = [&](uint32_t node, unsigned long long m) {
                     if (lane_id() == 0u) {
                         stack[sp][0] = node;
@@ -99,6 +99,7 @@ __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuf
                 descend = true;
             } else {
                 const uint32_t cnt = b & 0xFFFFu;
+                const bool hit = __builtin_amdgcn_inverse_ballot_w64(passed);
 #pragma unroll 1
                 for (uint32_t i = 0; i < cnt; i++) leaf(buf.prim_first + a + i, hit, sp);
             }
