@@ -79,7 +79,7 @@ def cpu_baseline(src, budget_s: float = 12.0, bsdf_probability: float = 1.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=768)
     ap.add_argument("--strata-per-step", type=int, default=256)
