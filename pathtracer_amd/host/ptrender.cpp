@@ -1,6 +1,6 @@
 // ptrender: the reference's main() without its window (src/main.rs:62-118) — build a scene
 // with the host scene API, build the BVHs, call Camera::render on a GPU and save the image
-// (PPM instead of the reference's strat.png).
+// (PNG as the reference's strat.png when the output name ends in .png, PPM otherwise).
 //
 //     ptrender [width] [spp] [out.ppm]                     the Cornell scene
 //     ptrender object <file.obj> [width] [spp] [out.ppm]   the Object scene on an .obj file

@@ -184,3 +184,47 @@ def test_a_scene_textured_from_a_file_renders_as_one_textured_from_memory(tmp_pa
     a = OracleScene(build(True)).render(0, 2, seed=1)["accum"]
     b = OracleScene(build(False)).render(0, 2, seed=1)["accum"]
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_renders_the_same_bits_with_texels_from_a_file(tmp_path):
+    from pathtracer_amd import scenes
+    from pathtracer_amd.core import HostScene, Renderer
+    rng = np.random.default_rng(6)
+    texels = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    p = str(tmp_path / "tex.png")
+    save_png(p, texels)
+
+    def render(from_file):
+        s = scenes.cornell(48, 16)
+        tex = s.image_file(p) if from_file else s.image(texels)
+        s.objects.add_sphere((278.0, 278.0, 278.0), 120.0, s.lambertian_texture(tex))
+        r = Renderer(HostScene(s))
+        r.render(0, 16, seed=3)
+        a = r.read_accum()[0]
+        r.close()
+        return a
+    a, b = render(True), render(False)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
+
+
+@pytest.mark.gpu
+def test_the_command_line_renderer_writes_png_and_ppm_with_the_same_pixels(tmp_path):
+    """ptrender is the reference's main() without its window (src/main.rs:62-118): Cornell scene through the C++ scene
+    API, Camera::render on the GPU, image saved as the reference saves it (PNG) or as PPM."""
+    import os
+    import subprocess
+    from pathtracer_amd import scenes
+    from pathtracer_amd.core import HostScene, Renderer
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pathtracer_amd", "ptrender")
+    png, ppm = str(tmp_path / "strat.png"), str(tmp_path / "strat.ppm")
+    for out in (png, ppm):
+        subprocess.run([exe, "64", "16", out], check=True, capture_output=True, timeout=120)
+    a, b = load_image(png), load_image(ppm)
+    assert a.shape == (64, 64, 3) and np.array_equal(a, b) and a.mean() > 5
+    # the same scene authored in Python, the same seed: the same 8-bit image
+    r = Renderer(HostScene(scenes.cornell(64, 16)))
+    r.render(0, 16, seed=0)
+    want = r.read_rgb8()
+    r.close()
+    assert np.array_equal(a, want)
