@@ -228,3 +228,51 @@ def test_the_command_line_renderer_writes_png_and_ppm_with_the_same_pixels(tmp_p
     want = r.read_rgb8()
     r.close()
     assert np.array_equal(a, want)
+
+
+def test_malformed_files_are_refused_not_crashed_on(tmp_path):
+    """Valid chunk checksums around broken contents: sizes that do not match the data, unknown filters, truncated and
+    over-long deflate streams, palettes that are too short, absurd headers.  Every file either loads or raises."""
+    import random
+    rnd = random.Random(11)
+    p = str(tmp_path / "m.png")
+    loaded = refused = 0
+    for _ in range(400):
+        color = rnd.choice([0, 2, 3, 4, 6])
+        depth = rnd.choice({0: [1, 2, 4, 8, 16], 2: [8, 16], 3: [1, 2, 4, 8], 4: [8, 16], 6: [8, 16]}[color])
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+        w, h = rnd.randint(1, 19), rnd.randint(1, 11)
+        stride = (w * ch * depth + 7) // 8
+        raw = bytearray()
+        for _y in range(h):
+            raw.append(rnd.randint(0, 4))
+            raw += bytes(rnd.getrandbits(8) for _ in range(stride))
+        defect = rnd.random()
+        head = [w, h, depth, color, 0, 0, 0]
+        if defect < 0.1:
+            raw[rnd.randrange(0, len(raw), stride + 1)] = rnd.choice([5, 77, 255])
+        elif defect < 0.2:
+            raw = raw[:-rnd.randint(1, stride)]
+        elif defect < 0.3:
+            raw += b"\0" * rnd.randint(1, 9)
+        elif defect < 0.4:
+            head[rnd.randrange(0, 2)] = rnd.choice([0, 2 ** 16, 2 ** 31 - 1, w + 1])
+        elif defect < 0.5:
+            head[rnd.randrange(2, 7)] = rnd.choice([0, 3, 5, 7, 32, 255])
+        z = zlib.compress(bytes(raw))
+        if 0.5 <= defect < 0.6:
+            z = z[:rnd.randint(0, len(z) - 1)]
+        data = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", *head))
+        if color == 3:
+            data += _chunk(b"PLTE", bytes(rnd.getrandbits(8) for _ in range(3 * rnd.choice([1, 2, 4, 16, 256]))))
+        data += _chunk(b"IDAT", z) + _chunk(b"IEND", b"")
+        if 0.6 <= defect < 0.65:
+            data = data[:rnd.randint(0, len(data) - 1)]
+        open(p, "wb").write(data)
+        try:
+            img = load_image(p)
+            assert img.shape == (h, w, 3)
+            loaded += 1
+        except PtError:
+            refused += 1
+    assert loaded > 100 and refused > 100, (loaded, refused)
