@@ -110,3 +110,35 @@ def test_nested_instances_first_hits_and_radiance_against_the_oracle(top_bvh):
     samples_agree(got, want, 0.999, f"nested top_bvh={top_bvh}")
     assert abs(got.mean() - want.mean()) < 0.02 * want.mean()
     r.close()
+
+
+@pytest.mark.gpu
+def test_nested_instances_in_the_reference_order_traversal_and_under_next_event_estimation():
+    """The per-lane reference-order loop (PT_OPT_TRAVERSAL = 1, also what finishes the last paths of a batch) and the
+    shadow rays of the next-event estimator go through the levels of a nested instance like the ray-drawing kernel."""
+    from oracle.pyoracle import OracleScene
+    from pathtracer_amd.core import PT_OPT_INTEGRATOR, PT_OPT_TRAVERSAL, Renderer
+    src = nested_scene(width=40, spp=16)
+    o = OracleScene(src)
+    host = HostScene(src)
+    rays = o.primary_rays()
+    ids, tuv = o.trace(rays)
+    for mode in (0, 1, 2):  # 2 asks for the wave-at-a-time search, which this scene cannot use: the per-lane kernel answers
+        r = Renderer(host, device=0)
+        r.set_option(PT_OPT_TRAVERSAL, mode)
+        h = r.trace(rays)
+        assert np.array_equal(h["prim_type"], ids[:, 0]), mode
+        assert np.array_equal(h["t"].view(np.uint32), tuv[:, 0].view(np.uint32)), mode
+        r.close()
+    r = Renderer(host, device=0)
+    r.set_option(PT_OPT_TRAVERSAL, 1)
+    got = np.nan_to_num(r.render_samples(0, 4, seed=8), nan=0.0, posinf=0.0, neginf=0.0)
+    want = np.nan_to_num(o.render(0, 4, seed=8, iterative=True, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    samples_agree(got, want, 0.999, "nested, reference-order traversal")
+    r.close()
+    r = Renderer(host, device=0)
+    r.set_option(PT_OPT_INTEGRATOR, 1)
+    got = np.nan_to_num(r.render_samples(0, 4, seed=8), nan=0.0, posinf=0.0, neginf=0.0)
+    want = np.nan_to_num(o.render(0, 4, seed=8, iterative=2, per_sample=True)["per_sample"], nan=0.0, posinf=0.0, neginf=0.0)
+    samples_agree(got, want, 0.999, "nested, next-event estimation")
+    r.close()
