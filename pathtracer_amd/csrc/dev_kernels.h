@@ -827,69 +827,116 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_shadow_walk(DevScene s
 // is all the schedules plan for.  `region`: the batch's region of the slot arrays.  The path's state stays
 // where its ray's queue entry was (position `pos` of the arrays of the next step's parity, and of the hit
 // arrays, which the finished step no longer needs); the queue entry becomes padding.
-template <bool MEDIA>
-__global__ __launch_bounds__(BLOCK) void k_finish(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, uint32_t region, f3 background,
-                                                  DevStats *stats) {
+// The scan comes first and on its own (k_finish_scan: a few registers, every wave of the chip; the path-finishing
+// code needs 256 and runs one wave per SIMD, which made its own scan of 14 M queue entries cost 220 us a step): it
+// lists (position, slot) of the region's entries in ps.finish_list and turns them into padding.  k_finish<MEDIA,
+// true> then finishes the listed paths; should more be left than the list holds (it holds 2^20), the rest stay in
+// the queue and k_finish<MEDIA, false>, which returns at once otherwise, scans for them as before.
+__global__ __launch_bounds__(BLOCK) void k_finish_scan(PathState ps, uint32_t bounce, uint32_t region, uint32_t k) {
     const uint32_t np = (bounce & 1u) ^ 1u;
     const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + np) * CTL_STRIDE], ps.max_ray_chunks);
+    uint32_t *count = &ps.ctl[(CTL_FINISH_COUNT + k) * CTL_STRIDE];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps.ctl[(CTL_FINISH_COUNT + (k ^ 1u)) * CTL_STRIDE] = 0u;  // for the scan after this one
+    uint4 *queue4 = (uint4 *)ps.ray_queue[np];
     uint32_t *queue = ps.ray_queue[np];
+    const uint32_t lo = region * ps.region_cap, hi = lo + ps.region_cap;  // below 2^31 (slots are)
+    const uint32_t n4 = n_chunks * (QUEUE_CHUNK / 4u);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n4; i += gridDim.x * BLOCK) {
+        const uint4 q = queue4[i];
+        const uint32_t s[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            if (s[j] < lo || s[j] >= hi) continue;  // QUEUE_EMPTY is above every slot
+            const uint32_t at = atomicAdd(count, 1u);
+            if (at < ps.finish_cap) {
+                ps.finish_list[at] = make_uint2(4u * i + j, s[j]);
+                queue[4u * i + j] = QUEUE_EMPTY;
+            }
+        }
+    }
+}
+
+// One leftover path to its end: the reference-order closest-hit loop and shade_vertex in turn.
+template <bool MEDIA>
+__device__ __forceinline__ void finish_path(const DevScene &sc, const DevCamera &cam, const PathState &ps, const BatchParams &bp, uint32_t np, const WorkList &wl,
+                                            uint32_t pos, uint32_t slot, f3 background, bool insts, LaneStack &st, TravCounters &tc, uint32_t &traced) {
+    for (bool first = true;; first = false) {
+        if (!first) traced++;
+        const float4 ro = ps.ray_o[np][pos], rd = ps.ray_d[np][pos];
+        TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
+        HitState h;
+        hit_world_prims(sc, r, h, st, tc);
+        if (insts) hit_world_insts(sc, r, h, st, tc);
+        if (sc.n_moving != 0u) hit_moving_spheres(sc, ps.beta[np][pos].w, r, h, tc);
+        int32_t mat = -1;
+        if (h.code != PTD_HIT_MISS) {
+            const uint32_t type = h.code & 3u;
+            mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
+        }
+        ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
+        ps.hit2[pos] = h.code;
+        VertexOut v;
+        v.alive = v.shadow = false;
+        if (mat < 0) {
+            if constexpr (MEDIA) {
+                shade_vertex<PTD_MAT_MEDIUM, false, true>(sc, cam, ps, bp, wl, pos, slot, v);
+            } else {  // src/camera.rs:371, :277-283
+                const float4 b = ps.beta[np][pos];
+                const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
+                ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
+            }
+        } else {
+            switch (sc.mats[mat].type) {
+#define FINISH(MT) case MT: shade_vertex<MT, false, MEDIA>(sc, cam, ps, bp, wl, pos, slot, v); break;
+                FINISH(PTS_MAT_LAMBERTIAN)
+                FINISH(PTS_MAT_METAL)
+                FINISH(PTS_MAT_DIELECTRIC)
+                FINISH(PTS_MAT_DIFFUSE_LIGHT)
+                FINISH(PTS_MAT_DISNEY)
+                FINISH(PTS_MAT_DISNEY_DIFFUSE)
+                FINISH(PTS_MAT_DISNEY_METAL)
+                FINISH(PTS_MAT_DISNEY_GLASS)
+                FINISH(PTS_MAT_DISNEY_CLEARCOAT)
+                FINISH(PTS_MAT_DISNEY_SHEEN)
+#undef FINISH
+                default: break;
+            }
+        }
+        if (!v.alive) break;
+        ps.ray_o[np][pos] = v.ray_o;
+        ps.ray_d[np][pos] = v.ray_d;
+        ps.beta[np][pos] = v.beta;
+    }
+}
+
+// LISTED: the paths k_finish_scan listed; otherwise: a scan of the queue, only where the list was too short.
+template <bool MEDIA, bool LISTED>
+__global__ __launch_bounds__(BLOCK) void k_finish(DevScene sc, DevCamera cam, PathState ps, BatchParams bp, uint32_t bounce, uint32_t region, f3 background,
+                                                  uint32_t k, DevStats *stats) {
+    const uint32_t found = ps.ctl[(CTL_FINISH_COUNT + k) * CTL_STRIDE];
+    if (!LISTED && found <= ps.finish_cap) return;
+    const uint32_t np = (bounce & 1u) ^ 1u;
     const WorkList wl{np, 0xFFFFFFFFu, FreshPaths{0u, 0u}};  // every position is a queue position
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     TravCounters tc{0, 0, 0, 0};
     const bool insts = sc.world.insts.prim_count != 0u;
     uint32_t traced = 0u;  // rays beyond the queued ones (those are already counted)
-    const uint32_t n_pos = n_chunks * QUEUE_CHUNK;
-    for (uint32_t pos = blockIdx.x * BLOCK + threadIdx.x; pos < n_pos; pos += gridDim.x * BLOCK) {
-        const uint32_t slot = queue[pos];
-        if (slot == QUEUE_EMPTY || slot / ps.region_cap != region) continue;
-        queue[pos] = QUEUE_EMPTY;
-        for (bool first = true;; first = false) {
-            if (!first) traced++;
-            const float4 ro = ps.ray_o[np][pos], rd = ps.ray_d[np][pos];
-            TravRay r = make_trav_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), 0.001f, INFINITY);
-            HitState h;
-            hit_world_prims(sc, r, h, st, tc);
-            if (insts) hit_world_insts(sc, r, h, st, tc);
-            if (sc.n_moving != 0u) hit_moving_spheres(sc, ps.beta[np][pos].w, r, h, tc);
-            int32_t mat = -1;
-            if (h.code != PTD_HIT_MISS) {
-                const uint32_t type = h.code & 3u;
-                mat = (type == PT_PRIM_TRI) ? sc.tri_mat[h.prim] : ((type == PT_PRIM_SPHERE) ? sc.sphere_mat[h.prim] : sc.quad_mat[h.prim]);
-            }
-            ps.hit[pos] = make_float4(r.t_max, h.u, h.v, __uint_as_float(h.prim));
-            ps.hit2[pos] = h.code;
-            VertexOut v;
-            v.alive = v.shadow = false;
-            if (mat < 0) {
-                if constexpr (MEDIA) {
-                    shade_vertex<PTD_MAT_MEDIUM, false, true>(sc, cam, ps, bp, wl, pos, slot, v);
-                } else {  // src/camera.rs:371, :277-283
-                    const float4 b = ps.beta[np][pos];
-                    const f3 l = (h.code == PTD_HIT_MISS) ? background : mk3(0.0f, 0.0f, 0.0f);
-                    ps.contrib[slot] = make_float4(b.x * l.x, b.y * l.y, b.z * l.z, 0.0f);
-                }
-            } else {
-                switch (sc.mats[mat].type) {
-#define FINISH(MT) case MT: shade_vertex<MT, false, MEDIA>(sc, cam, ps, bp, wl, pos, slot, v); break;
-                    FINISH(PTS_MAT_LAMBERTIAN)
-                    FINISH(PTS_MAT_METAL)
-                    FINISH(PTS_MAT_DIELECTRIC)
-                    FINISH(PTS_MAT_DIFFUSE_LIGHT)
-                    FINISH(PTS_MAT_DISNEY)
-                    FINISH(PTS_MAT_DISNEY_DIFFUSE)
-                    FINISH(PTS_MAT_DISNEY_METAL)
-                    FINISH(PTS_MAT_DISNEY_GLASS)
-                    FINISH(PTS_MAT_DISNEY_CLEARCOAT)
-                    FINISH(PTS_MAT_DISNEY_SHEEN)
-#undef FINISH
-                    default: break;
-                }
-            }
-            if (!v.alive) break;
-            ps.ray_o[np][pos] = v.ray_o;
-            ps.ray_d[np][pos] = v.ray_d;
-            ps.beta[np][pos] = v.beta;
+    if constexpr (LISTED) {
+        const uint32_t n = min(found, ps.finish_cap);
+        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+            const uint2 e = ps.finish_list[i];
+            finish_path<MEDIA>(sc, cam, ps, bp, np, wl, e.x, e.y, background, insts, st, tc, traced);
+        }
+    } else {
+        const uint32_t n_chunks = min(ps.ctl[(CTL_RAY_CHUNKS + np) * CTL_STRIDE], ps.max_ray_chunks);
+        uint32_t *queue = ps.ray_queue[np];
+        const uint32_t n_pos = n_chunks * QUEUE_CHUNK;
+        for (uint32_t pos = blockIdx.x * BLOCK + threadIdx.x; pos < n_pos; pos += gridDim.x * BLOCK) {
+            const uint32_t slot = queue[pos];
+            if (slot == QUEUE_EMPTY || slot / ps.region_cap != region) continue;
+            queue[pos] = QUEUE_EMPTY;
+            finish_path<MEDIA>(sc, cam, ps, bp, np, wl, pos, slot, background, insts, st, tc, traced);
         }
     }
     if (traced) atomicAdd(&stats->rays_total, (unsigned long long)traced);

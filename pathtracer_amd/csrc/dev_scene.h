@@ -114,7 +114,7 @@ constexpr uint32_t QUEUE_EMPTY = 0xFFFFFFFFu;
 // the copy the next kernel will fill.
 constexpr uint32_t CTL_STRIDE = 64;  // in 32-bit words
 constexpr uint32_t CTL_RAY_CHUNKS = 0;    // +parity: chunks in ray queue [parity]
-constexpr uint32_t CTL_RAY_CURSOR = 2;    // +parity: unused (the ray-drawing kernels take their work from CTL_WALK_CURSOR)
+constexpr uint32_t CTL_FINISH_COUNT = 2;  // +k: paths the k-th (mod 2) finishing scan of this path state has found (k_finish_scan)
 constexpr uint32_t CTL_SHADE_CHUNKS = 4;  // +2*queue+parity: chunks in material queue [queue]
 constexpr uint32_t BOUNCE_PROFILE_LEN = 1024;
 constexpr uint32_t CTL_SHADOW_CHUNKS = 4 + 2 * MAX_QUEUES;  // +parity: chunks in the shadow-ray queue filled during a step of that parity
@@ -155,6 +155,8 @@ struct PathState {
                            // whoever needs the ray again can go straight to the draws that made it
     float4 *contrib;  // [slot]: radiance of the finished path (xyz); zero between uses
     uint32_t *shade_queue[MAX_QUEUES];  // work-list positions by material type; only the queues of types in use exist
+    uint2 *finish_list;                 // (position, slot) of the paths a finishing scan has taken out of the ray queue; finish_cap entries
+    uint32_t finish_cap;
     uint32_t *ctl;                      // CTL_WORDS control words
     uint32_t *bounce_rays;              // [BOUNCE_PROFILE_LEN] rays traced at each bounce of the batch ([0] unused); may be null
     uint32_t *next_rays;                // rays the shading of this step has queued for the next one so far; may be null

@@ -145,6 +145,7 @@ struct pt_context {
         uint32_t ring_new[ROLL_RING] = {};
         uint64_t counted = 0;
         uint32_t known_rays = 0;
+        uint64_t finishes = 0;  // finishing scans on this path state so far (they take its two counters in turn)
         // How fast this scene's paths end: drain_rays[j] = rays still queued after tick last_start + j, where
         // last_start is the last tick that started a batch (so nothing but survivors is counted).
         uint64_t last_start = 0;
@@ -1193,6 +1194,13 @@ static int alloc_path_state(pt_context *ctx, std::vector<std::pair<void *, size_
     if ((rc = dev_alloc(ctx, pool, &ps.fresh_draws, n_fresh + 1u))) return rc;
     for (uint32_t q = 0; q < ctx->n_queues; q++)
         if ((rc = dev_alloc(ctx, pool, &ps.shade_queue[q], max_chunks * QUEUE_CHUNK))) return rc;
+    {
+        // PT_FINISH_LIST_CAP (tests only): a short list, so that the scan for what did not fit is exercised
+        const char *env = getenv("PT_FINISH_LIST_CAP");
+        const uint64_t want = env ? (uint64_t)std::max(1L, atol(env)) : (1ull << 20);
+        ps.finish_cap = (uint32_t)std::min<uint64_t>(want, std::max<uint64_t>(n_slots, 1));
+        if ((rc = dev_alloc(ctx, pool, &ps.finish_list, (size_t)ps.finish_cap))) return rc;
+    }
     if ((rc = dev_alloc(ctx, pool, &ps.ctl, (size_t)CTL_WORDS))) return rc;
     if ((rc = dev_alloc(ctx, pool, &ps.regions, (size_t)n_regions))) return rc;
     // radiance slots start at zero and are left at zero by whoever reads them (k_accumulate, pt_render_samples)
@@ -1374,10 +1382,16 @@ static void launch_shade_type(int type, const ShadeLaunch &l) {
 // Under light sampling a path can outlive max_depth (a vertex that samples a light resets the depth left to 2,
 // src/camera.rs:332): what is left of a batch when it is due is finished by k_finish.
 static bool paths_may_outlive_depth(const pt_context *ctx) { return !ctx->nee && ctx->bsdf_prob < 1.0f; }
-static void launch_finish(pt_context *ctx, hipStream_t st, const PathState &ps, const BatchParams &bp, uint32_t bounce, uint32_t region) {
+// k: 0 / 1 in turn for the calls on one path state (which of its two counters the scan uses).
+static void launch_finish(pt_context *ctx, hipStream_t st, const PathState &ps, const BatchParams &bp, uint32_t bounce, uint32_t region, uint32_t k) {
     const dim3 g(grid_fixed(ctx, ~0ull >> 1)), b(BLOCK);
-    if (ctx->scene.n_media != 0) hipLaunchKernelGGL((k_finish<true>), g, b, 0, st, ctx->scene, ctx->cam, ps, bp, bounce, region, ctx->cam.background, ctx->stats);
-    else hipLaunchKernelGGL((k_finish<false>), g, b, 0, st, ctx->scene, ctx->cam, ps, bp, bounce, region, ctx->cam.background, ctx->stats);
+    // the scan with every wave the chip holds; the listed paths (a handful, as a rule) with one workgroup per CU
+    hipLaunchKernelGGL(k_finish_scan, dim3((unsigned)ctx->n_cu * 8u), b, 0, st, ps, bounce, region, k);
+    const dim3 gl((unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu, ((uint64_t)ps.finish_cap + BLOCK - 1) / BLOCK));
+#define FIN(M, L, G) hipLaunchKernelGGL((k_finish<M, L>), G, b, 0, st, ctx->scene, ctx->cam, ps, bp, bounce, region, ctx->cam.background, k, ctx->stats)
+    if (ctx->scene.n_media != 0) { FIN(true, true, gl); FIN(true, false, g); }
+    else { FIN(false, true, gl); FIN(false, false, g); }
+#undef FIN
 }
 
 static uint64_t mix64_host(uint64_t z) {
@@ -1472,7 +1486,7 @@ static int run_batch(pt_context *ctx, pt_context::Pipe &pp, uint32_t first, uint
         if (ctx->nee) launch_shadow(ctx, st, g_ext, ps, b);
         if (prof) (void)hipEventRecord(get_event(pp, ev++), st);
     }
-    if (paths_may_outlive_depth(ctx)) launch_finish(ctx, st, ps, bp, depth - 1u, 0u);
+    if (paths_may_outlive_depth(ctx)) launch_finish(ctx, st, ps, bp, depth - 1u, 0u, 0u);
     if (bounces_out) *bounces_out = bounces;
     HIP_TRY(ctx, hipGetLastError());
     return PT_OK;
@@ -1663,7 +1677,7 @@ static int roll_step(pt_context *ctx, const BatchParams *nb, bool *started = nul
         // in stratum order over all pipes: ticks go round the pipes, so batches fall due in the order they started
         const pt_context::Due d = r.due.front();
         r.due.pop_front();
-        if (paths_may_outlive_depth(ctx) || r.n_regions < depth) launch_finish(ctx, st, ps, common, parity, d.region);
+        if (paths_may_outlive_depth(ctx) || r.n_regions < depth) launch_finish(ctx, st, ps, common, parity, d.region, (uint32_t)(r.finishes++ & 1u));
         if (ctx->last_accumulated) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->last_accumulated, 0));
         hipLaunchKernelGGL(k_accumulate, dim3(grid_for(ctx, common.npix)), dim3(BLOCK), 0, st, ps.contrib + (size_t)d.region * r.cap, ctx->accum, common.npix,
                            d.n_strata);

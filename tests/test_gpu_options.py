@@ -252,6 +252,32 @@ def test_accumulator_identical_however_early_the_last_paths_of_a_batch_are_finis
             assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"rolling={rolling} ticks={ticks}"
 
 
+def test_leftover_paths_beyond_the_finishing_list_are_found_by_the_full_scan(monkeypatch):
+    """What is left of a batch when it is due is listed by a scan and finished from the list; a list that is too short
+    (PT_FINISH_LIST_CAP, read when the path state is allocated) leaves the rest in the queue for the scanning form of
+    the finishing kernel.  With two launches per batch nearly every path is left over: same bits as without a limit
+    and as the schedule that never finishes early."""
+    from pathtracer_amd.core import PT_OPT_BATCH_TICKS, PT_OPT_ROLLING
+    src = scenes.small_mixed(40, 36)
+    accs = []
+    for cap, ticks in ((None, 1), (None, 2), ("8", 2), ("1", 3), ("100000", 2)):
+        if cap is None:
+            monkeypatch.delenv("PT_FINISH_LIST_CAP", raising=False)
+        else:
+            monkeypatch.setenv("PT_FINISH_LIST_CAP", cap)
+        r = _renderer(src)
+        r.set_option(PT_OPT_ROLLING, 3 * 40 * 40)
+        r.set_option(PT_OPT_BATCH_TICKS, ticks)
+        r.render(0, 20, seed=5)
+        r.render(20, 36, seed=5)
+        acc, n = r.read_accum()
+        assert n == 36
+        accs.append(acc)
+        r.close()
+    for a in accs[1:]:
+        assert np.array_equal(a.view(np.uint32), accs[0].view(np.uint32))
+
+
 def test_batch_length_is_learnt_from_the_first_drain():
     # A scene whose paths end quickly at a depth limit of 50: the first drain shows that nearly nothing is left
     # after a dozen launches, and the per-path sums shrink from 50 regions to that many (PT_OPT_BATCH_TICKS = 0,
