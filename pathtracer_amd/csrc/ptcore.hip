@@ -1384,11 +1384,14 @@ static void launch_shade_type(int type, const ShadeLaunch &l) {
 static bool paths_may_outlive_depth(const pt_context *ctx) { return !ctx->nee && ctx->bsdf_prob < 1.0f; }
 // k: 0 / 1 in turn for the calls on one path state (which of its two counters the scan uses).
 static void launch_finish(pt_context *ctx, hipStream_t st, const PathState &ps, const BatchParams &bp, uint32_t bounce, uint32_t region, uint32_t k) {
-    const dim3 g(grid_fixed(ctx, ~0ull >> 1)), b(BLOCK);
-    // the scan with every wave the chip holds; the listed paths (a handful, as a rule) with one workgroup per CU
+    const dim3 b(BLOCK);
+    // the scan with every wave the chip holds; the listed paths (a handful, as a rule) with one workgroup per CU, and
+    // so the scan for what the list could not hold, which as a rule finds nothing to do and returns (a larger grid
+    // of that 256-register kernel costs 30 us a step just to start and end)
     hipLaunchKernelGGL(k_finish_scan, dim3((unsigned)ctx->n_cu * 8u), b, 0, st, ps, bounce, region, k);
     const dim3 gl((unsigned)std::min<uint64_t>((uint64_t)ctx->n_cu, ((uint64_t)ps.finish_cap + BLOCK - 1) / BLOCK));
 #define FIN(M, L, G) hipLaunchKernelGGL((k_finish<M, L>), G, b, 0, st, ctx->scene, ctx->cam, ps, bp, bounce, region, ctx->cam.background, k, ctx->stats)
+    const dim3 g((unsigned)ctx->n_cu);
     if (ctx->scene.n_media != 0) { FIN(true, true, gl); FIN(true, false, g); }
     else { FIN(false, true, gl); FIN(false, false, g); }
 #undef FIN
