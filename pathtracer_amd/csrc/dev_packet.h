@@ -63,17 +63,23 @@ __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuf
     int sp = floor;
     uint32_t cur = 0u;
     unsigned long long mask = active;
+    // which lanes go against each axis: three masks for the whole search.  They choose the near child (src/bvh.rs:757)
+    // with scalar instructions, and in the plain form of the box test the near and far plane of each axis
+    const unsigned long long neg_x = __ballot(r.d.x < 0.0f), neg_y = __ballot(r.d.y < 0.0f), neg_z = __ballot(r.d.z < 0.0f);
     for (;;) {
         const float4 n0 = nodes[2u * cur], n1 = nodes[2u * cur + 1u];
         // every lane runs the test, the ones outside `mask` on whatever their registers hold (it reads no memory)
         float e;
-        const unsigned long long passed = (plain ? __ballot(slab_test_entry_plain(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, e)) : __ballot(slab_test(n0, n1, r))) & mask;
+        const unsigned long long passed =
+            (plain ? __ballot(slab_test_entry_signed(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, __builtin_amdgcn_inverse_ballot_w64(neg_x),
+                                                     __builtin_amdgcn_inverse_ballot_w64(neg_y), __builtin_amdgcn_inverse_ballot_w64(neg_z), e))
+                   : __ballot(slab_test(n0, n1, r))) &
+            mask;
         bool descend = false;
         if (passed != 0ull) {
             const uint32_t a = __float_as_uint(n1.z), b = __float_as_uint(n1.w);
             if (!(b & PT_NODE_LEAF)) {
-                const float da = (b == 0u) ? r.d.x : ((b == 1u) ? r.d.y : r.d.z);
-                const unsigned long long right_first = __ballot(da < 0.0f) & passed, left_first = passed & ~right_first;
+                const unsigned long long right_first = (b == 0u ? neg_x : (b == 1u ? neg_y : neg_z)) & passed, left_first = passed & ~right_first;
                 auto push = [&](uint32_t node, unsigned long long m) {
                     if (lane_id() == 0u) {
                         stack[sp][0] = node;

@@ -29,6 +29,7 @@ constexpr int LDS_LEVELS = PT_LDS_LEVELS;  // stack entries per lane held in LDS
 struct TravRay {
     f3 o, d, inv_d;
     float t_min, t_max;
+    uint32_t neg;  // bit a: d[a] < 0, what `ray.direction[axis] < 0.0` (src/bvh.rs:757) asks at every node with two children to visit
 };
 __device__ __forceinline__ TravRay make_trav_ray(f3 o, f3 d, float t_min, float t_max) {
     TravRay r;
@@ -37,6 +38,7 @@ __device__ __forceinline__ TravRay make_trav_ray(f3 o, f3 d, float t_min, float 
     r.inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // `1.0 / ray.direction[axis]`, same value at every node
     r.t_min = t_min;
     r.t_max = t_max;
+    r.neg = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
     return r;
 }
 
@@ -65,27 +67,40 @@ __shared__ uint2 g_lane_stack[LDS_LEVELS * BLOCK];
 // compiler folds the two into one flat_load, which pays for both paths on every pop.
 typedef __attribute__((address_space(1))) uint2 GlobalUint2;
 
+// "No entry in the register slot" is a value of the slot itself, not a flag beside it: a per-lane flag lives in a
+// scalar register pair, and every place where two control-flow paths meet merges it with three scalar instructions;
+// the scalar unit is shared by the four SIMDs of a CU (one instruction per cycle per CU, measured), so those count.
+constexpr uint32_t STACK_NO_TOP = 0xFFFFFFFFu;  // never pushed: node references and REF_* markers are all below it
+
 struct LaneStack {
     GlobalUint2 *overflow;  // [levels][stride]
     uint32_t stride;  // lanes in the launch
     uint32_t gtid;
-    uint32_t top_ref;
+    uint32_t top_ref;  // STACK_NO_TOP: the register slot is empty
     float top_e;
-    bool has_top;
     int sp;  // entries below the register slot
     __device__ __forceinline__ void init(uint2 *ovf, uint32_t lanes) {
         overflow = (GlobalUint2 *)ovf;
         stride = lanes;
         gtid = blockIdx.x * BLOCK + threadIdx.x;
-        has_top = false;
         sp = 0;
-        top_ref = 0;
+        top_ref = STACK_NO_TOP;
         top_e = 0.0f;
     }
+    __device__ __forceinline__ bool has_top() const { return top_ref != STACK_NO_TOP; }
+    __device__ __forceinline__ void clear() {
+        sp = 0;
+        top_ref = STACK_NO_TOP;
+    }
+    // The lanes that are here together nearly always all have their level in LDS: one scalar compare and branch
+    // decides that for the wave, and only a wave with a lane beyond LDS_LEVELS chooses per lane.
     __device__ __forceinline__ void spill_top() {
         const uint2 v = make_uint2(top_ref, __float_as_uint(top_e));
-        if (sp < LDS_LEVELS) g_lane_stack[sp * BLOCK + threadIdx.x] = v;
-        else {
+        if (__ballot(sp >= LDS_LEVELS) == 0ull) {
+            g_lane_stack[sp * BLOCK + threadIdx.x] = v;
+        } else if (sp < LDS_LEVELS) {
+            g_lane_stack[sp * BLOCK + threadIdx.x] = v;
+        } else {
             GlobalUint2 *p = overflow + ((size_t)(sp - LDS_LEVELS) * stride + gtid);
             p->x = v.x;
             p->y = v.y;
@@ -93,23 +108,24 @@ struct LaneStack {
         sp++;
     }
     __device__ __forceinline__ void push(uint32_t ref, float e) {
-        if (has_top) spill_top();
+        if (has_top()) spill_top();
         top_ref = ref;
         top_e = e;
-        has_top = true;
     }
     // Entries below `floor` belong to an enclosing traversal.
     __device__ __forceinline__ bool pop(int floor, uint32_t &ref, float &e) {
-        if (has_top) {
+        if (has_top()) {
             ref = top_ref;
             e = top_e;
-            has_top = false;
+            top_ref = STACK_NO_TOP;
             return true;
         }
         if (sp == floor) return false;
         sp--;
         uint2 v;
-        if (sp < LDS_LEVELS) {
+        if (__ballot(sp >= LDS_LEVELS) == 0ull) {
+            v = g_lane_stack[sp * BLOCK + threadIdx.x];
+        } else if (sp < LDS_LEVELS) {
             v = g_lane_stack[sp * BLOCK + threadIdx.x];
         } else {
             const GlobalUint2 *p = overflow + ((size_t)(sp - LDS_LEVELS) * stride + gtid);
@@ -119,11 +135,37 @@ struct LaneStack {
         e = __uint_as_float(v.y);
         return true;
     }
+    // push and pop without a branch per lane, for the persistent-wave kernels, where the lanes that are here together
+    // have each their own reason to be.  While every lane's level is in LDS (one scalar compare for the wave):
+    // a push writes the register slot to the level above the stack whether it holds an entry or not, and only the
+    // count says which; a pop reads the level below whether it will be needed or not.  Same stack contents.
+    __device__ __forceinline__ void push_flat(uint32_t ref, float e) {
+        if (__ballot(sp >= LDS_LEVELS) == 0ull) {
+            g_lane_stack[sp * BLOCK + threadIdx.x] = make_uint2(top_ref, __float_as_uint(top_e));
+            sp += has_top() ? 1 : 0;
+        } else if (has_top()) {
+            spill_top();
+        }
+        top_ref = ref;
+        top_e = e;
+    }
+    __device__ __forceinline__ bool pop_flat(uint32_t &ref, float &e) {
+        if (__ballot(sp > LDS_LEVELS) == 0ull) {
+            const uint2 v = g_lane_stack[(sp > 0 ? sp - 1 : 0) * BLOCK + threadIdx.x];
+            const bool top = has_top(), more = sp > 0;
+            ref = top ? top_ref : v.x;
+            e = top ? top_e : __uint_as_float(v.y);
+            sp -= (!top && more) ? 1 : 0;
+            top_ref = STACK_NO_TOP;
+            return top || more;
+        }
+        return pop(0, ref, e);
+    }
     // Start of a nested traversal: everything pushed so far must sit below its floor.
     __device__ __forceinline__ int enter() {
-        if (has_top) {
+        if (has_top()) {
             spill_top();
-            has_top = false;
+            top_ref = STACK_NO_TOP;
         }
         return sp;
     }
@@ -185,7 +227,22 @@ __device__ __forceinline__ bool slab_test_entry_plain(float lx, float ly, float 
     entry = t_min;
     return !(t_max < t_min);
 }
+// The same with the near and far plane of each axis chosen by the sign of the ray's direction instead of by
+// min / max: lo <= hi, and subtraction and multiplication round monotonically, so (lo - o) * inv <= (hi - o) * inv
+// exactly when inv > 0, and the smaller of the two is the one the sign names (equal values: either).  nx, ny, nz:
+// d < 0 on that axis, which for a plain ray is inv < 0.  A select issues at twice the rate of v_min_f32 / v_max_f32.
+__device__ __forceinline__ bool slab_test_entry_signed(float lx, float ly, float lz, float hx, float hy, float hz, const TravRay &r, bool nx, bool ny,
+                                                       bool nz, float &entry) {
+    const float ax = (lx - r.o.x) * r.inv_d.x, bx = (hx - r.o.x) * r.inv_d.x;
+    const float ay = (ly - r.o.y) * r.inv_d.y, by = (hy - r.o.y) * r.inv_d.y;
+    const float az = (lz - r.o.z) * r.inv_d.z, bz = (hz - r.o.z) * r.inv_d.z;
+    const float t_min = fmaxf(fmaxf(fmaxf(nx ? bx : ax, ny ? by : ay), nz ? bz : az), r.t_min);
+    const float t_max = fminf(fminf(fminf(nx ? ax : bx, ny ? ay : by), nz ? az : bz), r.t_max);
+    entry = t_min;
+    return !(t_max < t_min);
+}
 typedef float v2f __attribute__((ext_vector_type(2)));
+
 
 // Both boxes of a 64-byte node for a plain ray (slab_test_entry_plain twice).  The node keeps its twelve
 // coordinates as a = (lmin.x, lmin.y, lmax.x, lmax.y), b = (lmin.z, lmax.z, rmin.z, rmax.z), c = (rmin.x, rmin.y,

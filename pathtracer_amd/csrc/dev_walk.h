@@ -78,18 +78,28 @@ __device__ __forceinline__ uint32_t walk_begin(const DevBuffer &buf, const TravR
 
 // Next stacked node whose entry distance is still within reach; REF_RETURN when the
 // entries of the instance in progress are used up (that record stays on the stack until the
-// lane leaves the instance), REF_NONE when the stack is empty.
+// lane leaves the instance), REF_NONE when the stack is empty, REF_POP when the two entries looked at were both out
+// of reach (the lane goes on popping in the wave's next pass: a loop here would be a loop of the whole wave for the
+// sake of the few lanes that pop, with the scalar bookkeeping of a divergent loop).
+template <bool INSTANCES>
 __device__ __forceinline__ uint32_t walk_pop(LaneStack &st, const TravRay &r) {
-    uint32_t ref;
-    float e;
-    for (;;) {
-        if (!st.pop(0, ref, e)) return REF_NONE;
-        if (ref == REF_RETURN) {
-            st.push(ref, e);
-            return ref;
+    uint32_t out = REF_POP;
+#pragma unroll
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (out == REF_POP) {
+            uint32_t ref;
+            float e;
+            if (!st.pop_flat(ref, e)) {
+                out = REF_NONE;
+            } else if (INSTANCES && ref == REF_RETURN) {
+                st.push_flat(ref, e);
+                out = ref;
+            } else if (!(r.t_max < e)) {
+                out = ref;
+            }
         }
-        if (!(r.t_max < e)) return ref;
     }
+    return out;
 }
 
 // A build with PT_BOUNDS_CHECK verifies every node, primitive, instance and set index before
@@ -105,14 +115,13 @@ constexpr uint32_t WALK_MAX_PASSES = 1u << 20;
             bad_refs[3] = cur | ((unsigned long long)node_base << 32);                    \
             bad_refs[4] = ((unsigned long long)li << 32) | lend;                          \
             bad_refs[5] = inst_code | ((unsigned long long)prim_base << 32);              \
-            bad_refs[6] = (unsigned long long)st.sp | (st.has_top ? 1ull << 32 : 0ull);   \
+            bad_refs[6] = (unsigned long long)st.sp | (st.has_top() ? 1ull << 32 : 0ull);   \
             bad_refs[7] = slot | ((unsigned long long)child << 32);                       \
         }                                                                                 \
         phase = PHASE_DONE;                                                               \
         cur = REF_NONE;                                                                   \
         li = lend = 0u;                                                                   \
-        st.sp = 0;                                                                        \
-        st.has_top = false;                                                               \
+        st.clear();                                                                       \
         continue;                                                                         \
     }
 #else
@@ -284,6 +293,8 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
 #endif
                 float el, er;
                 bool hl, hr;
+                // (one copy of this step per form of the test, chosen for the wave outside the per-lane condition, and the
+                // same for the whole loop, were both measured 4 to 5 % slower)
                 if (plain) {
                     slab_test_two_plain(a, b, c, r, hl, el, hr, er);
                 } else {
@@ -297,9 +308,8 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                 cur = hl ? lref : rref;
                 if (!(hl || hr)) cur = REF_POP;
                 if (hl && hr) {
-                    const float da = (axis == 0) ? r.d.x : ((axis == 1) ? r.d.y : r.d.z);
-                    const bool neg = da < 0.0f;
-                    st.push(neg ? lref : rref, neg ? el : er);
+                    const bool neg = ((r.neg >> axis) & 1u) != 0u;
+                    st.push_flat(neg ? lref : rref, neg ? el : er);
                     cur = neg ? rref : lref;
                 }
                 open_leaf_ref();
@@ -346,8 +356,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                                 phase = PHASE_DONE;
                                 cur = REF_NONE;
                                 li = lend = 0u;
-                                st.sp = 0;
-                                st.has_top = false;
+                                st.clear();
                             }
                         }
                     }
@@ -355,7 +364,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
             }
             // (P) the one place where the stack is popped
             if (cur == REF_POP) {
-                cur = walk_pop(st, r);
+                cur = walk_pop<INSTANCES>(st, r);
                 open_leaf_ref();
             }
             // (C) nothing left in this buffer: on to the next one, or out of the instance
@@ -390,7 +399,7 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                 }
             } else if (cur == REF_NONE && phase < PHASE_DONE) {
                 // world level (inside an instance the bottom of the stack is REF_RETURN)
-                WALK_CHECK(inst_code == 0u && st.sp == 0 && !st.has_top, 7)
+                WALK_CHECK(inst_code == 0u && st.sp == 0 && !st.has_top(), 7)
                 phase++;
                 if (phase == 1u) begin_buffer(set.spheres);
                 else if (phase == 2u) begin_buffer(set.quads);
