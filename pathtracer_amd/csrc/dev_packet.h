@@ -126,7 +126,7 @@ __device__ __forceinline__ void packet_hit_set(const DevScene &sc, const DevSet 
     const ScalarF4 tri_hot = scalar_f4(sc.tri_hot), spheres = scalar_f4(sc.spheres), quads = scalar_f4(sc.quads);
     packet_traverse(sc, set.tris, active, plain, r, floor, [&](uint32_t g, bool on, int) {
         const float4 a = tri_hot[3u * g], b = tri_hot[3u * g + 1u], c = tri_hot[3u * g + 2u];
-        if (on) hit_tri(a, b, c, g, r, h, inst_code);
+                if (on) hit_tri_flat(a, b, c, g, r, h, inst_code);
     });
     packet_traverse(sc, set.spheres, active, plain, r, floor, [&](uint32_t g, bool on, int) {
         const float4 s = spheres[g];

@@ -288,6 +288,33 @@ __device__ __forceinline__ void hit_tri(float4 a, float4 b, float4 c, uint32_t g
     h.prim = g;
     h.code = PT_PRIM_TRI | inst_code;
 }
+// The same for the closest-hit kernels, without the early exits.  The reference leaves at the first condition that
+// fails; a wave leaves only when all its lanes do, which a handful of rays at one triangle each practically never
+// do together, so there the exits are only branches (three scalar instructions each).  Everything is computed and
+// the conditions, each as the reference states it (a NaN passes `u < 0 || u > 1` and fails the range test of t),
+// decide together whether the hit is taken.  (The shading kernels keep the form above for their light tests: this
+// one costs them 3 to 6 registers and with them a wave per SIMD.)
+__device__ __forceinline__ void hit_tri_flat(float4 a, float4 b, float4 c, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code) {
+    f3 v0 = mk3(a.x, a.y, a.z), e1 = mk3(a.w, b.x, b.y), e2 = mk3(b.z, b.w, c.x);
+    f3 e1_x_d = cross(e1, r.d);
+    float triple = dot(e1_x_d, e2);
+    float inv_triple = 1.0f / triple;
+    f3 s = r.o - v0;
+    f3 e2_x_s = cross(e2, s);
+    float u = dot(e2_x_s, r.d) * inv_triple;
+    float v = dot(e1_x_d, s) * inv_triple;
+    float t = dot(e2_x_s, e1) * inv_triple;
+    const bool take = (triple != 0.0f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | (u + v > 1.0f)) & ((r.t_min <= t) & (t <= r.t_max));
+    r.t_max = take ? t : r.t_max;
+    h.u = take ? u : h.u;
+    h.v = take ? v : h.v;
+    h.prim = take ? g : h.prim;
+    h.code = take ? (PT_PRIM_TRI | inst_code) : h.code;
+}
+__device__ __forceinline__ void hit_tri_flat(const DevScene &sc, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code, TravCounters &tc) {
+    tc.tris++;
+    hit_tri_flat(sc.tri_hot[3 * g], sc.tri_hot[3 * g + 1], sc.tri_hot[3 * g + 2], g, r, h, inst_code);
+}
 template <>
 __device__ __forceinline__ void hit_prim<PT_PRIM_TRI>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,
                                                       uint32_t inst_code, TravCounters &tc) {
@@ -342,6 +369,29 @@ __device__ __forceinline__ void hit_quad(float4 q0, float4 q1, float4 q2, float4
     h.v = beta;
     h.prim = g;
     h.code = PT_PRIM_QUAD | inst_code;
+}
+// Without the early exits, for the closest-hit kernels (see hit_tri_flat): the same conditions, each as the reference
+// states it, decide together.
+__device__ __forceinline__ void hit_quad_flat(float4 q0, float4 q1, float4 q2, float4 q3, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code) {
+    f3 origin = mk3(q0.x, q0.y, q0.z), qu = mk3(q0.w, q1.x, q1.y), qv = mk3(q1.z, q1.w, q2.x);
+    f3 normal = mk3(q2.y, q2.z, q2.w), w = mk3(q3.x, q3.y, q3.z);
+    float d = q3.w;
+    float denom = dot(normal, r.d);
+    float t = (d - dot(normal, r.o)) / denom;
+    f3 intersection = r.o + t * r.d;
+    f3 p = intersection - origin;
+    float alpha = dot(w, cross(p, qv));
+    float beta = dot(w, cross(qu, p));
+    const bool take = !(fabsf(denom) < 1e-6f) & !((t < r.t_min) | (t > r.t_max)) & ((0.0f <= alpha) & (alpha <= 1.0f)) & ((0.0f <= beta) & (beta <= 1.0f));
+    r.t_max = take ? t : r.t_max;
+    h.u = take ? alpha : h.u;
+    h.v = take ? beta : h.v;
+    h.prim = take ? g : h.prim;
+    h.code = take ? (PT_PRIM_QUAD | inst_code) : h.code;
+}
+__device__ __forceinline__ void hit_quad_flat(const DevScene &sc, uint32_t g, TravRay &r, HitState &h, uint32_t inst_code, TravCounters &tc) {
+    tc.quads++;
+    hit_quad_flat(sc.quads[4 * g], sc.quads[4 * g + 1], sc.quads[4 * g + 2], sc.quads[4 * g + 3], g, r, h, inst_code);
 }
 template <>
 __device__ __forceinline__ void hit_prim<PT_PRIM_QUAD>(const DevScene &sc, uint32_t g, TravRay &r, HitState &h,

@@ -347,9 +347,9 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                         } else {
                             const uint32_t type = phase & 3u;
                             WALK_CHECK(li < (type == 0u ? sc.n_tris : (type == 1u ? sc.n_spheres : sc.n_quads)), 4)
-                            if (type == 0u) hit_prim<PT_PRIM_TRI>(sc, li, r, h, inst_code, tc);
+                            if (type == 0u) hit_tri_flat(sc, li, r, h, inst_code, tc);
                             else if (type == 1u) hit_prim<PT_PRIM_SPHERE>(sc, li, r, h, inst_code, tc);
-                            else hit_prim<PT_PRIM_QUAD>(sc, li, r, h, inst_code, tc);
+                            else hit_quad_flat(sc, li, r, h, inst_code, tc);
                             li++;
                             if (li == lend) cur = REF_POP;
                             if (ANY_HIT && h.code != PTD_HIT_MISS) {  // nothing else about this ray matters
