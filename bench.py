@@ -27,6 +27,9 @@ B_NODE, B_TRI, B_SPHERE, B_QUAD, B_RAY_IO = 32, 36, 16, 64, 32 + 16
 HBM_PEAK_GBS = 8000.0
 # wave64 vector instructions the chip can issue per second: 256 CUs x 4 SIMDs x 2.4 GHz, one every 2 cycles
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
+# one scalar unit per CU, shared by its four SIMDs: a scalar instruction per 1.15 cycles per CU with eight waves per SIMD
+# issuing nothing else (tools/micro/valu_rate.hip, profiles/r03_valu_issue_rates.txt)
+SALU_ISSUE_PEAK = 256 * 2.4e9 / 1.15
 
 
 def csrc_sha256() -> str:
@@ -279,15 +282,41 @@ def main():
                 binding = {"bound": "valu_issue", "frac": valu_issue_frac, "lane_util": pc["lane_util"], "useful_lane_frac": valu_issue_frac * pc["lane_util"],
                            "peak": VALU_ISSUE_PEAK, "unit": "wave64 vector instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles)",
                            "valu_per_ray": pc["valu_per_ray"], "salu_per_ray": pc["salu_per_ray"], "waves_parked": pc["wait_share_of_wave_cycles"]}
+                # what a vector instruction of these kernels costs a SIMD on average (2 cycles for adds, multiplies, moves;
+                # 4 for min / max / compares / shifts; 8 for reciprocals: measured, tools/micro/valu_rate.hip) from the static
+                # mix of each kernel (tools/issue_mix.py), when that file was made from these sources
+                mix = {}
+                mfile = os.path.join(ROOT, "profiles", "r03_issue_mix.json")
+                if os.path.exists(mfile):
+                    with open(mfile) as f:
+                        mj = json.load(f)
+                    if mj.get("csrc_sha256") == csrc_sha256():
+                        mix = mj["kernels"]
+                inst = "<instances>" if host.desc.n_instances else ""
+                cyc_sum = valu_sum = 0.0
                 for kname in per_kernel:
                     k = pc.get("per_kernel", {}).get(kname)
                     if k:
                         pk = per_kernel[kname]
-                        f_issue = k["valu_per_ray"] * pk["rays_per_launch"] / (pk["ms_per_launch"] * 1e-3) / VALU_ISSUE_PEAK
+                        per_s = pk["rays_per_launch"] / (pk["ms_per_launch"] * 1e-3)
+                        f_issue = k["valu_per_ray"] * per_s / VALU_ISSUE_PEAK
                         pk["binding"] = {"bound": "valu_issue", "frac": f_issue, "lane_util": k["lane_util"], "useful_lane_frac": f_issue * k["lane_util"],
-                                         "valu_per_ray": k["valu_per_ray"], "salu_per_ray": k["salu_per_ray"]}
+                                         "valu_per_ray": k["valu_per_ray"], "salu_per_ray": k["salu_per_ray"],
+                                         "scalar_unit_frac": k["salu_per_ray"] * per_s / SALU_ISSUE_PEAK}
+                        m = mix.get(kname + inst) or mix.get(kname)
+                        if m:
+                            pk["binding"]["cycles_per_vector_instruction"] = m["cycles_per_vector_instruction"]
+                            pk["binding"]["vector_pipe_busy"] = f_issue * m["cycles_per_vector_instruction"] / 2.0
+                            cyc_sum += m["cycles_per_vector_instruction"] * k["valu_per_ray"] * pk["rays"]
+                            valu_sum += k["valu_per_ray"] * pk["rays"]
                         pk["traffic"] = k["hbm_bytes_per_ray"] * pk["rays_per_launch"]
                         pk["hbm_counter_frac"] = pk["traffic"] / (pk["ms_per_launch"] * 1e-3) / (HBM_PEAK_GBS * 1e9)
+                binding["scalar_unit_frac"] = pc["salu_per_ray"] * rays_per_launch / launch_s / SALU_ISSUE_PEAK
+                if valu_sum > 0:
+                    binding["cycles_per_vector_instruction"] = cyc_sum / valu_sum
+                    binding["vector_pipe_busy"] = valu_issue_frac * binding["cycles_per_vector_instruction"] / 2.0
+                    binding["note"] = ("frac prices every vector instruction at 2 cycles per SIMD; vector_pipe_busy with what the kernels' own mix costs "
+                                       "(profiles/r03_issue_mix.json); scalar_unit_frac is the CU's shared scalar unit")
                 counters_from = f"profiles/{os.path.basename(cfile)}: rocprofv3 --pmc passes of this command with these kernel sources (per-ray figures x this run's rays per launch / this run's launch time)"
             else:
                 counters_from = f"profiles/{os.path.basename(cfile)} was recorded with other kernel sources: not used"

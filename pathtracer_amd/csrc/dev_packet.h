@@ -64,7 +64,9 @@ __device__ __forceinline__ void packet_traverse(const DevScene &sc, const DevBuf
     uint32_t cur = 0u;
     unsigned long long mask = active;
     // which lanes go against each axis: three masks for the whole search.  They choose the near child (src/bvh.rs:757)
-    // with scalar instructions, and in the plain form of the box test the near and far plane of each axis
+    // with scalar instructions (per visit this was two compares and two selects to pick the direction's component by
+    // the node's axis, a third compare and a ballot), and in the plain form of the box test the near and far plane of
+    // each axis
     const unsigned long long neg_x = __ballot(r.d.x < 0.0f), neg_y = __ballot(r.d.y < 0.0f), neg_z = __ballot(r.d.z < 0.0f);
     for (;;) {
         const float4 n0 = nodes[2u * cur], n1 = nodes[2u * cur + 1u];

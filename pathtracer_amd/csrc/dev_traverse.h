@@ -230,7 +230,10 @@ __device__ __forceinline__ bool slab_test_entry_plain(float lx, float ly, float 
 // The same with the near and far plane of each axis chosen by the sign of the ray's direction instead of by
 // min / max: lo <= hi, and subtraction and multiplication round monotonically, so (lo - o) * inv <= (hi - o) * inv
 // exactly when inv > 0, and the smaller of the two is the one the sign names (equal values: either).  nx, ny, nz:
-// d < 0 on that axis, which for a plain ray is inv < 0.  A select issues at twice the rate of v_min_f32 / v_max_f32.
+// d < 0 on that axis, which for a plain ray is inv < 0.  With the three conditions as wave masks in scalar registers
+// the wave-at-a-time kernel's launches are 2 % shorter than with min / max (measured; in isolation a select on a mask
+// in scalar registers issues at the rate of v_min_f32, tools/micro/valu_rate.hip, so the gain is in what the compiler
+// makes of the rest); the same in the ray-drawing kernel, whose lanes change rays, was within noise and is not used.
 __device__ __forceinline__ bool slab_test_entry_signed(float lx, float ly, float lz, float hx, float hy, float hz, const TravRay &r, bool nx, bool ny,
                                                        bool nz, float &entry) {
     const float ax = (lx - r.o.x) * r.inv_d.x, bx = (hx - r.o.x) * r.inv_d.x;

@@ -34,6 +34,18 @@
 #define LSH(k) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a##k));
 #define MOV(k) asm volatile("v_mov_b32 %0, %1" : "+v"(a##k) : "v"(b));
 #define CND(k) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##k) : "v"(b) : );
+#define CNDS(k) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a##k) : "v"(b) : );
+#define SUB(k) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define MAXF(k) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define MIN3(k) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(a##k) : "v"(b), "v"(c));
+#define XOR(k) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a##k) : "v"(b));
+#define BFE(k) asm volatile("v_bfe_u32 %0, %0, 3, 7" : "+v"(a##k));
+#define LSHLADD(k) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a##k) : "v"(b));
+#define ADD3(k) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a##k) : "v"(b), "v"(c));
+#define SQRT(k) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a##k));
+#define DIVFIX(k) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a##k) : "v"(b), "v"(c));
+#define DIVSCALE(k) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a##k) : "v"(b) : "vcc");
+#define CVT(k) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a##k));
 #define CMP(k) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a##k), "v"(b) : "vcc");
 #define CMPS(k) asm volatile("v_cmp_lt_f32 s[20:21], %0, %1" : : "v"(a##k), "v"(b) : "s20", "s21");
 #define CMPCND(k) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a##k) : "v"(b) : "vcc");
@@ -55,6 +67,18 @@ KERNEL(k_and, REP8(AND))
 KERNEL(k_lsh, REP8(LSH))
 KERNEL(k_mov, REP8(MOV))
 KERNEL(k_cnd, REP8(CND))
+KERNEL(k_cnds, REP8(CNDS))
+KERNEL(k_sub, REP8(SUB))
+KERNEL(k_maxf, REP8(MAXF))
+KERNEL(k_min3, REP8(MIN3))
+KERNEL(k_xor, REP8(XOR))
+KERNEL(k_bfe, REP8(BFE))
+KERNEL(k_lshladd, REP8(LSHLADD))
+KERNEL(k_add3, REP8(ADD3))
+KERNEL(k_sqrt, REP8(SQRT))
+KERNEL(k_divfix, REP8(DIVFIX))
+KERNEL(k_divscale, REP8(DIVSCALE))
+KERNEL(k_cvt, REP8(CVT))
 KERNEL(k_cmp, REP8(CMP))
 KERNEL(k_cmps, REP8(CMPS))
 KERNEL(k_cmpcnd, REP8(CMPCND))
@@ -88,7 +112,9 @@ int main() {
     hipMalloc(&sink, 4);
     const Row rows[] = {{"v_add_f32", k_add, 8}, {"v_mul_f32", k_mul, 8}, {"v_fma_f32", k_fma, 8}, {"v_min_f32", k_min, 8},
                         {"v_max3_f32", k_max3, 8}, {"v_add_u32", k_iadd, 8}, {"v_and_b32", k_and, 8}, {"v_lshlrev_b32", k_lsh, 8},
-                        {"v_mov_b32", k_mov, 8}, {"v_cndmask_b32 (vcc)", k_cnd, 8}, {"v_cmp_lt_f32 -> vcc", k_cmp, 8},
+                        {"v_mov_b32", k_mov, 8}, {"v_cndmask_b32 (vcc)", k_cnd, 8}, {"v_cndmask_b32 (sgpr pair)", k_cnds, 8}, {"v_sub_f32", k_sub, 8}, {"v_max_f32", k_maxf, 8},
+                        {"v_min3_f32", k_min3, 8}, {"v_xor_b32", k_xor, 8}, {"v_bfe_u32", k_bfe, 8}, {"v_lshl_add_u32", k_lshladd, 8}, {"v_add3_u32", k_add3, 8},
+                        {"v_sqrt_f32", k_sqrt, 8}, {"v_div_fixup_f32", k_divfix, 8}, {"v_div_scale_f32", k_divscale, 8}, {"v_cvt_f32_u32", k_cvt, 8}, {"v_cmp_lt_f32 -> vcc", k_cmp, 8},
                         {"v_cmp_lt_f32 -> sgpr pair", k_cmps, 8}, {"v_cmp + v_cndmask (dependent through vcc)", k_cmpcnd, 16},
                         {"v_sub + v_mul (dependent)", k_submul, 16}, {"v_mad_u32_u24", k_madu, 8}, {"v_mul_lo_u32", k_mullo, 8},
                         {"v_rcp_f32", k_rcp, 8}, {"v_pk_add_f32", k_pkadd, 8}, {"s_and_b64 (scalar)", k_sbal, 8},
