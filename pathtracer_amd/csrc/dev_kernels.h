@@ -329,7 +329,8 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DevScene sc, DevCamera cam, Pa
 // MOVING: the scene has moving spheres (pts_moving_sphere): a finished ray is tested against them, where
 // they are at its path's time, before it is classified.
 // FRESH: the launch may carry paths that start with it (false: they are in k_extend_packet's hands, fp.n_new is 0).
-template <bool INSTANCES, bool MOVING, bool FRESH>
+// TAIL: walk_tail_applies(sc.world), checked by the host: the world's few spheres and quads are tested when a ray is handed on.
+template <bool INSTANCES, bool MOVING, bool FRESH, bool TAIL = false>
 __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene sc, DevCamera cam, PathState ps, uint32_t bounce, f3 background, FreshPaths fp,
                                                                       DevStats *stats) {
     const WorkList full = work_list(ps, bounce, fp);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) WALK_OCCUPANCY void k_extend_walk(DevScene s
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
     // a lane's ray is named by its position in the work list
-    walk_world<INSTANCES>(
+    walk_world<INSTANCES, false, TAIL>(
         sc, n_pieces, &ps.ctl[(CTL_WALK_CURSOR + WORK_LISTS * wl.parity) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &pos, TravRay &r) {
             if (wl.slot(ps, i) == QUEUE_EMPTY) return false;
@@ -1065,11 +1066,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace_packet(DevScene sc, PathState p
         }
     }
 }
-template <bool INSTANCES>
+template <bool INSTANCES, bool TAIL = false>
 __global__ __launch_bounds__(BLOCK) void k_trace_walk(DevScene sc, PathState ps, uint32_t n, DevStats *stats) {
     LaneStack st;
     st.init(ps.overflow, ps.overflow_stride);
-    walk_world<INSTANCES>(
+    walk_world<INSTANCES, false, TAIL>(
         sc, (n + QUEUE_CHUNK - 1u) / QUEUE_CHUNK * (QUEUE_CHUNK / 64u), &ps.ctl[(CTL_WALK_CURSOR + 0) * CTL_STRIDE], ps.refill_below, ps.leaf_batch, st, stats->bad_refs,
         [&](uint32_t i, uint32_t &slot, TravRay &r) {
             slot = ps.ray_queue[0][i];

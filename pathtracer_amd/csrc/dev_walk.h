@@ -67,6 +67,13 @@ constexpr uint32_t REF_RETURN = 0xFFFFFFFDu;  // bottom of an instance's part of
 constexpr uint32_t REF_POP = 0xFFFFFFFCu;     // `cur` only: the lane needs the next entry of its stack
 constexpr uint32_t PHASE_INSTS = 3u, PHASE_CHILD = 4u, PHASE_DONE = 7u, PHASE_IDLE = 8u;
 
+// A buffer that needs no search: empty, without a tree, or with a tree that is one leaf.
+__host__ __device__ inline bool walk_one_leaf(const DevBuffer &b) {
+    return b.prim_count == 0u || b.tree == 0u || (b.tree == 1u && (b.root_ref & WIDE_LEAF) != 0u && b.root_ref < REF_POP);
+}
+// walk_world's TAIL form applies to a world without instances whose sphere and quad buffers are of that kind.
+__host__ __device__ inline bool walk_tail_applies(const DevSet &world) { return world.insts.prim_count == 0u && walk_one_leaf(world.spheres) && walk_one_leaf(world.quads); }
+
 // First node of a buffer for ray r: the buffer's own early-outs and the root's box.
 __device__ __forceinline__ uint32_t walk_begin(const DevBuffer &buf, const TravRay &r) {
     if (buf.prim_count == 0) return REF_NONE;
@@ -135,7 +142,10 @@ constexpr uint32_t WALK_MAX_PASSES = 1u << 20;
 // distance.  The work is `n_pieces` pieces of 64 entries; `cursor`: WORK_LISTS control words,
 // CTL_STRIDE apart, zero before the launch, that count the blocks of pieces handed out.  `bad_refs` is only touched in the bounds-checking build.
 // ANY_HIT: a ray is finished by the first primitive it hits (shadow rays: is there anything in [t_min, t_max]?).
-template <bool INSTANCES, bool ANY_HIT = false, class Source, class Reload, class Sink>
+// TAIL: the caller has checked that the world has no instances and that its sphere and quad buffers are of the kind
+// described below (walk_tail_applies); the code for them is then compiled in, and left out otherwise (it costs the
+// other scenes registers: 4 to 5 % of their rate when it was always there).
+template <bool INSTANCES, bool ANY_HIT = false, bool TAIL = false, class Source, class Reload, class Sink>
 __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces, uint32_t *cursor, int refill_below, int leaf_batch,
                                            LaneStack &st, unsigned long long *bad_refs, Source &&source, Reload &&reload, Sink &&sink) {
     const DevSet &set = sc.world;
@@ -145,6 +155,12 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
     for (uint32_t i = threadIdx.x; i < 4u * top_n; i += blockDim.x) g_top_nodes[i] = sc.wide[4 * (size_t)top_base + i];
     __syncthreads();
 #endif
+    // Sphere and quad buffers whose tree is one leaf (or that are empty, or have no tree) need no search: once a lane is
+    // through the triangles its ray is finished as far as the loop below is concerned, and what PrimitiveBuffer::hit
+    // does next, the root's box and the leaf's primitives in order, spheres before quads, is done for all the rays that
+    // leave together, just before they are handed on.  In the loop those few tests took a lane four or five passes, in
+    // primitive steps of their own kind with a handful of lanes.
+    constexpr bool tail_after = TAIL && !INSTANCES;
     constexpr uint32_t PIECES = QUEUE_CHUNK / 64u;
     const uint32_t claim = n_pieces >= 2u * PIECES * wave_count() ? PIECES : 1u;  // pieces per atomic
     // the cursors live in memory every XCD shares: waves that cannot get a piece do not poll them
@@ -401,7 +417,8 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
                 // world level (inside an instance the bottom of the stack is REF_RETURN)
                 WALK_CHECK(inst_code == 0u && st.sp == 0 && !st.has_top(), 7)
                 phase++;
-                if (phase == 1u) begin_buffer(set.spheres);
+                if constexpr (tail_after) phase = PHASE_DONE;
+                else if (phase == 1u) begin_buffer(set.spheres);
                 else if (phase == 2u) begin_buffer(set.quads);
                 else if (INSTANCES && phase == PHASE_INSTS) begin_buffer(set.insts);
                 else phase = PHASE_DONE;
@@ -412,6 +429,23 @@ __device__ __forceinline__ void walk_world(const DevScene &sc, uint32_t n_pieces
         }
 
         // ---- finished rays leave
+        if constexpr (tail_after) {
+            const bool fin = phase == PHASE_DONE;
+            auto leaf_of = [&](const DevBuffer &b, auto &&test) {
+                if (b.prim_count == 0u) return;
+                bool go = fin;
+                if (b.tree != 0u) {  // walk_begin: the root's box
+                    float e;
+                    go = go && slab_test_entry(b.rmin[0], b.rmin[1], b.rmin[2], b.rmax[0], b.rmax[1], b.rmax[2], r, e);
+                }
+                const uint32_t first = b.prim_first + (b.tree != 0u ? (b.root_ref & 0xFFFFFFu) : 0u), count = b.tree != 0u ? ((b.root_ref >> 24) & 0x7Fu) : b.prim_count;
+#pragma unroll 1
+                for (uint32_t i = 0; i < count; i++)
+                    if (go && !(ANY_HIT && h.code != PTD_HIT_MISS)) test(first + i);
+            };
+            leaf_of(set.spheres, [&](uint32_t g) { hit_prim<PT_PRIM_SPHERE>(sc, g, r, h, 0u, tc); });
+            leaf_of(set.quads, [&](uint32_t g) { hit_quad_flat(sc, g, r, h, 0u, tc); });
+        }
         sink(phase == PHASE_DONE, slot, r, h);
         if (phase == PHASE_DONE) phase = PHASE_IDLE;
     }

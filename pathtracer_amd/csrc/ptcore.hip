@@ -1299,12 +1299,13 @@ static void launch_extend(pt_context *ctx, hipStream_t st, int grid, const PathS
             const int beside = mostly_new ? 4 : 5;
             if (beside < ctx->blocks_per_cu) g = dim3(std::min<unsigned>(g.x, (unsigned)grid_fixed(ctx, ~0ull >> 1, beside)));
         }
-#define EXW(I, M, F) hipLaunchKernelGGL((k_extend_walk<I, M, F>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, walk_fp, ctx->stats)
-#define EXWF(I, M) do { if (walk_fp.n_new != 0u) EXW(I, M, true); else EXW(I, M, false); } while (0)
+#define EXW(I, M, F, T) hipLaunchKernelGGL((k_extend_walk<I, M, F, T>), g, b, 0, st, ctx->scene, ctx->cam, ps, bounce, bg, walk_fp, ctx->stats)
+#define EXWF(I, M, T) do { if (walk_fp.n_new != 0u) EXW(I, M, true, T); else EXW(I, M, false, T); } while (0)
+        const bool tail = !insts && walk_tail_applies(ctx->scene.world);  // its few spheres and quads need no search
         if (ctx->scene.n_moving != 0) {
-            if (insts) EXWF(true, true); else EXWF(false, true);
+            if (insts) EXWF(true, true, false); else if (tail) EXWF(false, true, true); else EXWF(false, true, false);
         } else {
-            if (insts) EXWF(true, false); else EXWF(false, false);
+            if (insts) EXWF(true, false, false); else if (tail) EXWF(false, false, true); else EXWF(false, false, false);
         }
 #undef EXWF
 #undef EXW
@@ -1933,6 +1934,7 @@ static int trace_first_hit(pt_context *ctx, const float *rays, const float *time
             else hipLaunchKernelGGL((k_trace_packet<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
         } else if (ctx->use_wide()) {
             if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
+            else if (walk_tail_applies(ctx->scene.world)) hipLaunchKernelGGL((k_trace_walk<false, true>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
             else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n, ctx->stats);
         } else {
             hipLaunchKernelGGL(k_trace, g, b, 0, st, ctx->scene, pp.ps, (uint32_t)n);
@@ -2035,6 +2037,7 @@ int pt_trace_first_hit_static(pt_context *ctx, const float *rays_device, uint64_
     const bool insts = ctx->scene.world.insts.prim_count != 0;
     if (ctx->use_wide()) {
         if (insts) hipLaunchKernelGGL((k_trace_walk<true>), g, b, 0, st, ctx->scene, ps, (uint32_t)n, ctx->stats);
+        else if (walk_tail_applies(ctx->scene.world)) hipLaunchKernelGGL((k_trace_walk<false, true>), g, b, 0, st, ctx->scene, ps, (uint32_t)n, ctx->stats);
         else hipLaunchKernelGGL((k_trace_walk<false>), g, b, 0, st, ctx->scene, ps, (uint32_t)n, ctx->stats);
     } else {
         hipLaunchKernelGGL(k_trace, g, b, 0, st, ctx->scene, ps, (uint32_t)n);
