@@ -39,9 +39,8 @@ def csrc_sha256():
     d = os.path.join(ROOT, "pathtracer_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".h", ".hip")):
-            h.update(name.encode())
             with open(os.path.join(d, name), "rb") as f:
-                h.update(f.read())
+                h.update(name.encode() + b"\0" + f.read())  # bench.py's csrc_sha256
     return h.hexdigest()
 
 
