@@ -20,8 +20,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {
-    "k_extend_walk": "_Z13k_extend_walkILb0ELb0ELb0EE",
-    "k_extend_walk<instances>": "_Z13k_extend_walkILb1ELb0ELb0EE",
+    "k_extend_walk": "_Z13k_extend_walkILb0ELb0ELb0ELb0EE",
+    "k_extend_walk<tail>": "_Z13k_extend_walkILb0ELb0ELb0ELb1EE",
+    "k_extend_walk<instances>": "_Z13k_extend_walkILb1ELb0ELb0ELb0EE",
     "k_extend_packet": "_Z15k_extend_packetILb0ELb0EE",
     "k_extend_packet<instances>": "_Z15k_extend_packetILb1ELb0EE",
     "k_shadow_walk": "_Z13k_shadow_walkILb0EE",
