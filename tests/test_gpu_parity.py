@@ -62,6 +62,72 @@ def test_random_and_degenerate_rays_both_traversals(name):
         assert bits_equal(h["u"][m], tuv[m, 1]) and bits_equal(h["v"][m], tuv[m, 2])
 
 
+def test_spheres_and_quads_tested_when_a_ray_is_handed_on_keep_the_reference_order():
+    """A world without instances whose sphere and quad buffers are one leaf each: the ray-drawing kernel tests them after
+    its loop, for all the rays that leave it together.  PrimitiveBuffer::hit (src/objects.rs:191-197) takes triangles,
+    spheres, quads in that order and a later hit at the same distance replaces an earlier one: a quad lying in the plane
+    of the triangles, a sphere touching it and one cutting it make such ties, and rays along the axes, rays that graze
+    the buffers' boxes and rays that start on the surfaces must come out as the oracle's, id for id and bit for bit."""
+    from pathtracer_amd.core import PT_OPT_TRAVERSAL
+    from pathtracer_amd.scene_src import CameraSrc, SceneSource
+    s = SceneSource()
+    s.name = "tail"
+    grey, red = s.lambertian((0.5, 0.5, 0.5)), s.lambertian((0.8, 0.2, 0.2))
+    n = 24
+    g = np.linspace(-3.0, 3.0, n + 1, dtype=np.float32)
+    X, Z = np.meshgrid(g, g, indexing="ij")
+    P = np.stack([X, np.zeros_like(X), Z], axis=-1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    tris = np.concatenate([np.stack([a, b, c], axis=-2).reshape(-1, 3, 3), np.stack([a, c, d], axis=-2).reshape(-1, 3, 3)]).astype(np.float32)
+    s.objects.add_triangles(tris, None, None, grey)
+    s.objects.add_quad((-1.0, 0.0, -1.0), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), red)      # in the triangles' plane
+    s.objects.add_quad((-2.0, 0.5, -2.0), (0.0, 1.5, 0.0), (0.0, 0.0, 4.0), red)      # a wall
+    s.objects.add_sphere((1.5, 0.5, 1.5), 0.5, red)                                   # touches the plane
+    s.objects.add_sphere((-1.5, 0.25, 1.5), 0.5, red)                                 # cuts it
+    s.objects.add_sphere((0.0, 2.0, 0.0), 0.25, red)
+    s.lights.add_sphere((0.0, 8.0, 0.0), 1.0, s.diffuse_light((5.0, 5.0, 5.0)))
+    s.objects.build_bvh = True
+    s.camera = CameraSrc(1.0, 32, 40.0, (0.0, 4.0, 8.0), (0.0, 0.0, 0.0), 10.0, 0.0, 16, 8, (0.1, 0.1, 0.1))
+    o, r = _pair(s)
+    rng = np.random.default_rng(11)
+    rays = _random_rays(rng, 40000, -3.5, 3.5)
+    down = np.zeros((6000, 8), np.float32)  # straight down onto the plane, the quad in it, the touching sphere's pole
+    down[:, 0], down[:, 2] = rng.uniform(-3.2, 3.2, 6000), rng.uniform(-3.2, 3.2, 6000)
+    down[:2000, 0], down[:2000, 2] = rng.uniform(-1.0, 1.0, 2000), rng.uniform(-1.0, 1.0, 2000)
+    down[2000:2200, 0], down[2000:2200, 2] = 1.5, 1.5
+    down[:, 1], down[:, 4], down[:, 6], down[:, 7] = 3.0, -1.0, 0.001, np.inf
+    rays = np.concatenate([rays, down])
+    ids0, tuv0 = o.trace(rays)
+    hit = ids0[:, 0] >= 0
+    onsurf = rays[hit][:15000].copy()
+    onsurf[:, :3] = onsurf[:, :3] + tuv0[hit][:15000, 0:1] * onsurf[:, 3:6]
+    onsurf[:, 3:6] = rng.normal(size=(onsurf.shape[0], 3)).astype(np.float32)
+    onsurf[:, 7] = np.inf
+    rays = np.concatenate([rays, onsurf])
+    ids, tuv = o.trace(rays)
+    assert (ids[:, 0] == 0).sum() > 1000 and (ids[:, 0] == 1).sum() > 1000 and (ids[:, 0] == 2).sum() > 1000
+    for mode in (0, 1, 2):
+        r.set_option(PT_OPT_TRAVERSAL, mode)
+        h = r.trace(rays)
+        assert np.array_equal(h["prim_type"], ids[:, 0]), mode
+        assert np.array_equal(h["prim_id"], ids[:, 1]), mode
+        assert bits_equal(h["t"], tuv[:, 0]), mode
+        m = ids[:, 0] >= 0
+        assert bits_equal(h["u"][m], tuv[m, 1]) and bits_equal(h["v"][m], tuv[m, 2])
+    # and rendered: the accumulator of the ray-drawing kernels equals that of the reference-order kernels bit for bit,
+    # and per-path radiance agrees with the oracle's recursion
+    accs = []
+    for mode in (0, 1):
+        r.set_option(PT_OPT_TRAVERSAL, mode)
+        r.reset_accum()
+        r.render(0, 9, seed=9)
+        accs.append(r.read_accum()[0])
+    assert bits_equal(accs[0], accs[1])
+    ref = o.render(0, 4, seed=9, iterative=True, per_sample=True)["per_sample"]
+    r.set_option(PT_OPT_TRAVERSAL, 0)
+    samples_agree(np.nan_to_num(r.render_samples(0, 4, seed=9)), np.nan_to_num(ref), 0.999, "one-leaf spheres and quads")
+
+
 def test_traversal_counters_equal_the_oracles_on_identical_rays():
     """With depth 1 only camera rays are traced, and those are bit-identical on both sides, so the
     device's reference-order counters must equal the oracle's exactly."""
