@@ -51,3 +51,5 @@ resources:
 # Microbenchmarks behind design decisions (run on the GPU box).
 tools/micro/atomic_rate: tools/micro/atomic_rate.hip
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -o $@ $<
+tools/micro/valu_rate: tools/micro/valu_rate.hip
+	$(HIPCC) -O2 -w --offload-arch=$(ARCH) -o $@ $<
