@@ -186,8 +186,10 @@ enum {
                                            2: as 0, and pt_trace_first_hit / _at search for 64 consecutive rays at a time the
                                            way PT_OPT_PACKET does for camera rays (scenes without device-built BVHs), so
                                            that search can be checked on any rays */
-    PT_OPT_PIPES = 5,                   /* streams the batches are spread over; 1..8, default 1 with the rolling schedule
-                                           (PT_OPT_ROLLING) and 4 without */
+    PT_OPT_PIPES = 5,                   /* streams the batches are spread over; 1..8.  Default without the rolling schedule: 4.
+                                           With it (PT_OPT_ROLLING), until this option is set: 1 where a launch starts more
+                                           than 12 M paths, 2 where it starts fewer (image and stratum ranges so small that a
+                                           launch's last rays leave most of the chip idle; twice the path state) */
     PT_OPT_REFILL_BELOW = 6,            /* a traversing wave with fewer busy lanes than this fetches new rays; 1..64, default 32 */
     PT_OPT_LEAF_BATCH = 7,              /* lanes that wait at a leaf before the wave runs a primitive test; 1..64, default 16 */
     PT_OPT_BLOCKS_PER_CU = 8,           /* resident workgroups per CU of the traversal kernels; 1..5, default 5 */
