@@ -1733,7 +1733,8 @@ static uint32_t roll_strata_now(pt_context *ctx) {
     uint64_t have = free_b;
     for (int p = 0; p < ctx->n_roll_pipes; p++)
         for (const auto &a : ctx->rolls[p].allocs) have += a.second;  // what is there would be replaced
-    const uint64_t budget = have / 2 / (uint64_t)ctx->n_roll_pipes;
+    // (while the number of pipes follows the launch size, the budget is that of two: small launches get a second pipe)
+    const uint64_t budget = have / 2 / (uint64_t)(ctx->roll_pipes_auto ? 2 : ctx->n_roll_pipes);
     auto bytes = [&](uint64_t kk) { return roll_bytes(ctx, ctx->roll_regions(), npix * kk, roll_live(ctx, depth, npix * kk)); };
     // slots are 32-bit numbers, and every region of a pipe has them
     auto too_big = [&](uint64_t kk) { return bytes(kk) > budget || (uint64_t)ctx->roll_regions() * npix * kk > (1ull << 31); };
