@@ -47,6 +47,41 @@ def test_accumulator_identical_for_any_number_of_batches_in_flight():
             assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32)), f"pipes={pipes} max_paths={max_paths}"
 
 
+def test_pipes_chosen_by_launch_size_give_the_sums_of_one_pipe():
+    """Unless PT_OPT_PIPES says how many, the rolling schedule runs two pipes where a launch starts at most 12 M paths and
+    one above that.  A small render (two pipes by that rule), the same with one pipe and with three set by hand, and a
+    context whose first request is small and whose second is large enough to cross the threshold (the second pipe is given
+    up at a synchronisation point) must all produce the same bits."""
+    from pathtracer_amd.core import PT_OPT_PIPES
+    src = scenes.cornell(64, 36)
+    accs = {}
+    for pipes in (None, 1, 3):
+        r = _renderer(src)
+        if pipes is not None:
+            r.set_option(PT_OPT_PIPES, pipes)
+        r.render(0, 7, seed=5)
+        r.render(7, 36, seed=5)
+        accs[pipes], n = r.read_accum()
+        assert n == 36
+    assert np.array_equal(accs[None].view(np.uint32), accs[1].view(np.uint32))
+    assert np.array_equal(accs[None].view(np.uint32), accs[3].view(np.uint32))
+    # across the threshold: 2 strata of 2048 x 1536 are 6.3 M paths per launch, 5 are 15.7 M
+    big = scenes.cornell(2048, 9)
+    big.camera.aspect_ratio = 2048.0 / 1536.0
+    outs = []
+    for pipes in (None, 1):
+        r = _renderer(big)
+        if pipes is not None:
+            r.set_option(PT_OPT_PIPES, pipes)
+        r.render(0, 2, seed=3)
+        r.render(2, 4, seed=3)
+        r.render(4, 9, seed=3)
+        acc, n = r.read_accum()
+        assert n == 9
+        outs.append(acc)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
 def test_first_hits_identical_for_any_refill_and_leaf_batch():
     from oracle.pyoracle import OracleScene
     from pathtracer_amd.core import PT_OPT_LEAF_BATCH, PT_OPT_REFILL_BELOW
